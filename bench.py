@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path on MI355X (driver contract).
+
+  python bench.py --gpus N --steps K --warmup W [--workload pathtrace|mandelbrot|mandelbrot_ds]
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one synthetic batch:
+  pathtrace (default, BASELINE config K2): render the 900 x 600 default scene at 500 spp — one fused
+      HIP launch per rank — and, for N > 1, gather the fp32 row tiles to rank 0 over RCCL and
+      re-assemble the storage buffer there.
+  mandelbrot (BASELINE config K1): 3200 x 2400, M = 1000, fp32.  mandelbrot_ds: the two-float variant.
+Weak scaling: per-GPU work is fixed, the image grows to W x (H*N) rows, interleaved 16-row blocks per
+rank (every pixel is keyed by its absolute coordinates, so tiling never changes a pixel's arithmetic;
+samples are never split across GPUs — the fp32 accumulation order is part of the parity contract).
+
+Output buffers are resident in HBM (torch tensors); there are no inputs besides 432 B of scene
+constants.  The timed region is bracketed by barrier + torch.cuda.synchronize() on both sides; the
+value is whole-job units / max-over-ranks time.  One JSON line is printed by rank 0.
+
+`roofline`: fp32 VALU (neither HBM nor MFMA bounds this path: 16 B written per pixel, no contraction).
+   achieved = algorithmic fp32 flops per launch (flops/unit from the oracle's op counters) /
+   mean kernel time measured with HIP events on the launch stream; peak = 157.3 TFLOP/s (FMA-counted,
+   MI355X_MICROARCH.md).  `lane_ops` adds the issue-slot view (78.6e12 lane-ops/s at 2.4 GHz): with
+   no contraction allowed every flop occupies a slot, so 0.5 of the FMA-counted peak is the ceiling.
+`cpu_baseline`: the CPU oracle (a port, not the reference's Vulkan build — lavapipe/glslang are absent)
+   timed on this host's cores over a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Algorithmic work per unit (frozen from the oracle's per-op counters).
+FLOPS_PER_PIXEL_ITER_F32 = 8        # mandelbrot.comp:43-44 in reuse-optimal form
+FLOPS_PER_PIXEL_ITER_DS = 142       # 3 ds_mul(32) + 4 ds_add/sub(11) + 2
+FLOPS_PER_SAMPLE_PT = 3811.0        # oracle counters, 900x600 default scene (add+mul+div+sqrt+trig+pow)
+PEAK_FP32_TFLOPS = 157.3            # MI355X vector fp32, FMA counted as 2 (v_pk_fma_f32 only)
+PEAK_LANE_OPS = 78.6e12             # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (v_add/v_mul issue rate)
+
+K2 = dict(W=900, H=600, spp=500)
+K1 = dict(W=3200, H=2400, M=1000)
+K4_VIEW = dict(centre=(-0.7436438870371587, 0.13182590420531198), scale=(1e-8, 1e-8 * 2.0 / 3.0))
+ROW_BLOCK = 16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="pathtrace", choices=["pathtrace", "mandelbrot", "mandelbrot_ds"])
+    ap.add_argument("--math", default="fast", choices=["fast", "strict"],
+                    help="path tracer math mode: fast = gfx950 hardware transcendentals (toleranced parity), "
+                         "strict = IEEE + mc math (bit-identical to the oracle)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--spp", type=int, default=None, help="override spp (diagnostics only; invalidates the headline)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as entry
+    B = entry.load_package().bindings
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n = args.gpus
+    if world != n:
+        if world == 1 and n > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        n = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    if n > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=n, device_id=torch.device("cuda", local_rank))
+    ctx = B.Context(local_rank)
+    dev_name, cus, _ = ctx.device_info()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- workload ---------------------------------------------------------------------------------
+    wl = args.workload
+    if wl == "pathtrace":
+        W, Hbase, spp = K2["W"], K2["H"], args.spp or K2["spp"]
+        H = Hbase * n
+        math_mode = B.PT_MATH_FAST if args.math == "fast" else B.PT_MATH_STRICT
+        p = B.pathtrace_params(W, H, spp, math_mode=math_mode, row_begin=rank * ROW_BLOCK, row_end=H,
+                               row_block=ROW_BLOCK if n > 1 else 0, row_stride=ROW_BLOCK * n if n > 1 else 0)
+        if n == 1:
+            p.row_begin, p.row_end = 0, H
+        units_per_step = W * H * spp                         # samples
+        flops_per_unit = FLOPS_PER_SAMPLE_PT
+        metric, unit = "path-traced samples/s", "samples/s"
+        workload_name = f"pathtrace {W}x{H} spp{spp} default-scene math={args.math}"
+    else:
+        W, Hbase, M = K1["W"], K1["H"], K1["M"]
+        H = Hbase * n
+        ds = wl == "mandelbrot_ds"
+        kw = dict(max_iter=M, row_begin=rank * ROW_BLOCK, row_end=H, row_block=ROW_BLOCK if n > 1 else 0,
+                  row_stride=ROW_BLOCK * n if n > 1 else 0)
+        if ds:
+            kw.update(precision=B.PRECISION_DS, centre=K4_VIEW["centre"], scale=K4_VIEW["scale"])
+        p = B.mandelbrot_params(W, H, **kw)
+        if n == 1:
+            p.row_begin, p.row_end = 0, H
+        units_per_step = None                                # pixel-iters: data dependent, counted after the run
+        flops_per_unit = FLOPS_PER_PIXEL_ITER_DS if ds else FLOPS_PER_PIXEL_ITER_F32
+        metric, unit = "Mandelbrot pixel-iters/s", "pixel-iters/s"
+        workload_name = f"mandelbrot{'_ds' if ds else ''} {W}x{H} M{M}"
+
+    rows_local = B.tile_rows(p)
+    rows_padded = int(B.lib().mc_tile_rows(0, H, ROW_BLOCK, ROW_BLOCK * n)) if n > 1 else rows_local
+    tile = torch.zeros((rows_padded, W, 4), dtype=torch.float32, device="cuda")
+    iters_t = torch.zeros((rows_padded, W), dtype=torch.int32, device="cuda") if wl != "pathtrace" else None
+    gathered = full = None
+    if n > 1 and rank == 0:
+        gathered = [torch.empty_like(tile) for _ in range(n)]
+        gathered_flat = torch.empty((n, rows_padded, W, 4), dtype=torch.float32, device="cuda")
+        full = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+
+    ev_k0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev_k1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev_k0[i].record()
+        if wl == "pathtrace":
+            ctx.pathtrace_device(p, tile.data_ptr(), stream=stream)
+        else:
+            ctx.mandelbrot_device(p, tile.data_ptr(), iters_t.data_ptr(), stream=stream)
+        if i is not None:
+            ev_k1[i].record()
+        if n > 1:
+            dist.gather(tile, gathered if rank == 0 else None, dst=0)
+            if rank == 0:
+                torch.stack(gathered, out=gathered_flat)
+                ctx.deinterleave_rows_device(gathered_flat.data_ptr(), W, H, n, ROW_BLOCK, rows_padded, 16,
+                                             full.data_ptr(), stream=stream)
+
+    def fence():
+        if n > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if n > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_k0, ev_k1)]))
+
+    # ---- units ------------------------------------------------------------------------------------
+    if wl == "pathtrace":
+        local_units = W * rows_local * p.spp
+    else:
+        it = iters_t[:rows_local].to(torch.int64)
+        M = p.max_iter
+        local_units = int(torch.where(it < M, it + 1, torch.full_like(it, M)).sum().item())   # executed loop bodies
+        if n > 1:
+            tot = torch.tensor([local_units], dtype=torch.int64, device="cuda")
+            dist.all_reduce(tot)
+            units_per_step = int(tot.item())
+        else:
+            units_per_step = local_units
+    value = units_per_step * args.steps / dt
+
+    out = None
+    if rank == 0:
+        achieved_tflops = local_units * flops_per_unit / (kernel_ms * 1e-3) / 1e12
+        kern = {"pathtrace": "pathtrace_kernel", "mandelbrot": "mandelbrot_kernel<StateF32>",
+                "mandelbrot_ds": "mandelbrot_kernel<StateDS>"}[wl]
+        out = {
+            "metric": metric, "value": value, "unit": unit, "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload_name, "image": [W, H], "rows_per_gpu": rows_local,
+                       "tiling": "whole image" if n == 1 else f"interleaved {ROW_BLOCK}-row blocks, RCCL gather to rank 0",
+                       "device": dev_name, "compute_units": cus},
+            "roofline": {"bound": "valu", "kernel": kern, "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": None,
+                         "kernel_ms": kernel_ms, "flops_per_unit": flops_per_unit,
+                         "lane_ops": {"achieved": achieved_tflops * 1e12, "peak": PEAK_LANE_OPS,
+                                      "frac": achieved_tflops * 1e12 / PEAK_LANE_OPS,
+                                      "note": "parity forbids contraction: one issue slot per flop"}},
+        }
+
+    # ---- secondary metric + CPU baseline: rank 0, N = 1 only, outside the timed region ------------------
+    if rank == 0 and n == 1 and not args.no_secondary and wl == "pathtrace":
+        q = B.mandelbrot_params(K1["W"], K1["H"], max_iter=K1["M"])
+        rg = torch.empty((K1["H"], K1["W"], 4), dtype=torch.float32, device="cuda")
+        itr = torch.empty((K1["H"], K1["W"]), dtype=torch.int32, device="cuda")
+        for _ in range(3):
+            ctx.mandelbrot_device(q, rg.data_ptr(), itr.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        reps = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ctx.mandelbrot_device(q, rg.data_ptr(), itr.data_ptr(), stream=stream)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        it64 = itr.to(torch.int64)
+        pi = int(torch.where(it64 < K1["M"], it64 + 1, torch.full_like(it64, K1["M"])).sum().item())
+        tf = pi * FLOPS_PER_PIXEL_ITER_F32 / (ms * 1e-3) / 1e12
+        out["secondary"] = {"metric": "Mandelbrot pixel-iters/s", "value": pi / (ms * 1e-3), "unit": "pixel-iters/s",
+                            "workload": f"mandelbrot {K1['W']}x{K1['H']} M{K1['M']} fp32", "pixel_iters": pi, "kernel_ms": ms,
+                            "roofline": {"bound": "valu", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": tf / PEAK_FP32_TFLOPS, "lane_ops_frac": tf * 1e12 / PEAK_LANE_OPS}}
+
+    if rank == 0 and n == 1 and not args.no_cpu_baseline:
+        O = entry.load_oracle()   # TEST INFRASTRUCTURE, used here only as the timed CPU baseline
+        threads = O.hardware_threads()
+        if wl == "pathtrace":
+            s_spp = 4
+            t = time.perf_counter()
+            O.pathtrace(W, H, p.spp, math_mode=O.MATH_LIBM, sample_begin=0, sample_end=s_spp, nthreads=threads)
+            cdt = time.perf_counter() - t
+            out["cpu_baseline"] = {"value": W * H * s_spp / cdt, "unit": unit, "cores": threads, "kind": "port",
+                                   "sample": f"samples 0..{s_spp - 1} of {p.spp} over the full {W}x{H} image "
+                                             f"({W * H * s_spp} samples, {cdt:.1f} s)"}
+        else:
+            rows = list(range(0, H, 16))   # every 16th row: same interior/exterior mix as the full image
+            t = time.perf_counter()
+            tot = 0
+            view = O.make_view(*(K4_VIEW["centre"] + K4_VIEW["scale"])) if wl == "mandelbrot_ds" else O.REF_VIEW
+            for r in rows:
+                itc = O.mandelbrot_iters(W, H, p.max_iter, view=view, precision=int(wl == "mandelbrot_ds"), row_begin=r,
+                                         row_end=r + 1, nthreads=1)
+                tot += O.mandel_pixel_iters(itc, p.max_iter)
+            cdt = time.perf_counter() - t
+            out["cpu_baseline"] = {"value": tot / cdt, "unit": unit, "cores": 1, "kind": "port",
+                                   "sample": f"every 16th row of the {W}x{H} image ({tot} pixel-iters, {cdt:.1f} s)"}
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if n > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,177 @@
+/*
+ * mc_compute.h — C ABI of libmc_compute.so: the MI355X (gfx950) replacement for the Vulkan compute
+ * runtime + GLSL shaders of pjhusky/vulkan-compute-tests.
+ *
+ * The reference has no FFI; the boundary this library sits behind is the C++ virtual surface of
+ * `VulkanComputeApp` (src/vulkanComputeApp.h:30-67) as driven by src/main.cpp:28-33.  Each entry
+ * point below cites the reference code it replaces (paths relative to the reference checkout).
+ * The C++ mirror of the reference interface lives in vulkan-compute-tests_amd/host/ and calls only
+ * these functions; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions: plain pointers and sizes, no exceptions, no STL, no torch types.  Every function
+ * returns MC_OK (0) or an mc_status error code; mc_error_string() renders it; mc_last_error_detail()
+ * gives the HIP/RCCL message of the last failure on the calling thread.  All calls are blocking
+ * unless the name ends in _async.  A context is not thread-safe; use one per thread/device.
+ *
+ * Buffer layout (the reference's storage-buffer contract): row-major, one `vec4` fp32 per pixel
+ * (16 B, src/mandelbrotApp.h:187-189, shaders/mandelbrot.comp:10-17,59, shaders/pathTracer.comp:71),
+ * rows are STORAGE rows (for the path tracer storage row r holds pix.y = H-1-r, pathTracer.comp:349).
+ * Tile calls take [row_begin,row_end) in storage rows and a pointer to the FIRST ROW OF THE TILE.
+ */
+#ifndef MC_COMPUTE_H_
+#define MC_COMPUTE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MC_ABI_VERSION 1
+
+typedef enum mc_status {
+    MC_OK = 0,
+    MC_ERR_INVALID_ARGUMENT = 1, /* NULL pointer, zero size, row range outside the image ...          */
+    MC_ERR_NO_DEVICE = 2,        /* no HIP device / device index out of range (vulkanComputeApp.cpp:78) */
+    MC_ERR_HIP = 3,              /* a HIP runtime call failed; see mc_last_error_detail()             */
+    MC_ERR_RCCL = 4,             /* an RCCL call failed                                               */
+    MC_ERR_UNSUPPORTED = 5,      /* e.g. scene larger than the on-chip scene store                    */
+    MC_ERR_OUT_OF_MEMORY = 6
+} mc_status;
+
+typedef struct mc_context mc_context; /* opaque: device, stream, scratch, LUT cache, (optional) RCCL comms */
+
+/* ---- lifecycle: replaces VulkanComputeApp::init() (vulkanComputeApp.cpp:443-449: createInstance,
+ *      findPhysicalDevice, createDevice) and cleanupVulkanResources() (:673-695) -------------------- */
+int mc_abi_version(void);
+int mc_device_count(int* count);
+int mc_context_create(int device, mc_context** out_ctx);
+int mc_context_destroy(mc_context* ctx);
+const char* mc_error_string(int status);
+const char* mc_last_error_detail(void);
+/* Device name / CU count of the context's device (vulkanComputeApp.cpp:163 picks devices[0]). */
+int mc_context_device_info(mc_context* ctx, char* name, size_t name_len, int* compute_units, int* clock_khz);
+
+/* ---- Mandelbrot: replaces shaders/mandelbrot.comp:21-60 + the dispatch recorded in
+ *      MandelbrotApp::createCommandBuffer (src/mandelbrotApp.h:137-147) ----------------------------- */
+enum { MC_PRECISION_F32 = 0, MC_PRECISION_DS = 1 /* two-float, emulateDouble.h.glsl:59-139 */ };
+enum {
+    MC_MANDEL_FMA = 1u << 0 /* NON-PARITY diagnostic: allow fp contraction in the fp32 loop */
+};
+
+typedef struct mc_mandelbrot_params {
+    uint32_t width, height;   /* WIDTH/HEIGHT (mandelbrot.comp:5-6); reference 2000x2000 (main.cpp:20)  */
+    uint32_t max_iter;        /* M (mandelbrot.comp:40); reference 128                                   */
+    uint32_t precision;       /* MC_PRECISION_*                                                         */
+    /* c = centre + (uv - 0.5) * scale (mandelbrot.comp:38); reference centre (-0.445, 0), scale 2.34   */
+    /* on both axes.  *_lo are the low words for MC_PRECISION_DS (hi=(float)d, lo=(float)(d-hi)).       */
+    float centre_x_hi, centre_x_lo, centre_y_hi, centre_y_lo;
+    float scale_x_hi, scale_x_lo, scale_y_hi, scale_y_lo;
+    float k_color[4];         /* push constant kColor (mandelbrotApp.h:139); reference {0.1,0.7,0.6,0}   */
+    uint32_t row_begin, row_end; /* storage rows rendered by this call; 0,height for the whole image     */
+    uint32_t row_block, row_stride; /* 0,0: the tile is the contiguous rows [row_begin,row_end).          */
+                              /* Otherwise the tile is the rows row_begin + k*row_stride + j (j<row_block,   */
+                              /* < row_end), stored compactly: tile row k*row_block + j (interleaved row     */
+                              /* blocks, one residue class per GPU; see mc_tile_rows)                        */
+    uint32_t flags;           /* MC_MANDEL_*                                                            */
+    uint32_t reserved;
+} mc_mandelbrot_params;
+
+/* Fills p with the reference defaults for a W x H image (main.cpp:20, mandelbrot.comp:38-40). */
+int mc_mandelbrot_default_params(uint32_t width, uint32_t height, mc_mandelbrot_params* p);
+
+/* Host-buffer form (what MandelbrotApp::run + vkMapMemory give the reference, mandelbrotApp.h:149-155):
+ * out_rgba_f32: (row_end-row_begin)*width*4 floats, may be NULL; out_iters: same pixel count of
+ * uint32 iteration counts n in [0,max_iter], may be NULL.  At least one must be non-NULL. */
+int mc_mandelbrot_render(mc_context* ctx, const mc_mandelbrot_params* p, float* out_rgba_f32, uint32_t* out_iters);
+
+/* Device-buffer form (buffers already resident in HBM; pointers are device pointers on ctx's device).
+ * Asynchronous on `stream` (a hipStream_t, NULL = the context's stream); either output may be NULL. */
+int mc_mandelbrot_render_device_async(mc_context* ctx, const mc_mandelbrot_params* p, void* d_rgba_f32,
+                                      void* d_iters, void* stream);
+
+/* The (max_iter+1)-entry colour table: entry n = vec4 written for iteration count n
+ * (mandelbrot.comp:50-56, evaluated on the host in fp32 source order).  lut_f32: (max_iter+1)*4. */
+int mc_mandelbrot_colour_lut(uint32_t max_iter, const float k_color[4], float* lut_f32);
+
+/* ---- Path tracer: replaces shaders/pathTracer.comp:343-458 and the spp-dispatch loop of
+ *      PathtracerApp::createCommandBuffer (src/pathtracerApp.h:358-378), fused into one launch ------ */
+enum {
+    MC_PT_MATH_STRICT = 0, /* IEEE div/sqrt + the explicit "mc math" sin/cos/pow: bit-identical to the oracle */
+    MC_PT_MATH_FAST = 1    /* gfx950 hardware rcp/rsq/sqrt/sin/cos/exp/log: toleranced parity    */
+};
+
+typedef struct mc_pathtrace_params {
+    uint32_t width, height;            /* push constant imgdim (pathtracerApp.h:44-47,58-59)            */
+    uint32_t spp;                      /* push constant samps.y (pathtracerApp.h:61; main.cpp:22)        */
+    uint32_t sample_begin, sample_end; /* samps.x range rendered by this call; 0,spp = whole render.     */
+                                       /* sample_begin>0 continues the accumulator already in the buffer */
+    uint32_t max_depth;                /* maxDepth, 12 (pathTracer.comp:367)                             */
+    uint32_t row_begin, row_end;       /* storage rows; 0,height for the whole image                    */
+    uint32_t row_block, row_stride;    /* interleaved row blocks, as in mc_mandelbrot_params             */
+    uint32_t math_mode;                /* MC_PT_MATH_*                                                   */
+    uint32_t flags;
+} mc_pathtrace_params;
+
+int mc_pathtrace_default_params(uint32_t width, uint32_t height, uint32_t spp, mc_pathtrace_params* p);
+
+/* The reference's default scene tables (pathtracerApp.h:14-39): 12 floats per object
+ * (plane: equation.xyzw | emission.xyz0 | colour.rgb,material; sphere: centre.xyz,radius | ... ). */
+int mc_pathtrace_default_scene(const float** planes, uint32_t* n_planes, const float** spheres, uint32_t* n_spheres);
+
+/* Host-buffer form: planes/spheres are the host tables PathtracerApp::preRun memcpy's into its SSBOs
+ * (pathtracerApp.h:152-161,189-198); out_rgba_f32 receives (row_end-row_begin)*width*4 floats. */
+int mc_pathtrace_render(mc_context* ctx, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
+                        const float* spheres, uint32_t n_spheres, float* out_rgba_f32);
+
+/* Device-buffer form: d_rgba_f32 is a device pointer to the tile; scene tables are still host
+ * pointers (432 B, passed as kernel constants).  Asynchronous on `stream` (NULL = context stream). */
+int mc_pathtrace_render_device_async(mc_context* ctx, const mc_pathtrace_params* p, const float* planes,
+                                     uint32_t n_planes, const float* spheres, uint32_t n_spheres, void* d_rgba_f32,
+                                     void* stream);
+
+/* ---- Host post-process on the GPU: replaces the scalar loops of
+ *      getRenderedImage (mandelbrotApp.h:149-170, pathtracerApp.h:202-223) and the 180-degree
+ *      rotation (pathtracerApp.h:236-243).  u8 = (uint8_t)(scale*c) with the x86-64 semantics the
+ *      reference binary has (cvttss2si, low byte), alpha = 255.  rotate180 != 0 applies the PT swap. */
+int mc_convert_rgba8_device_async(mc_context* ctx, const void* d_rgba_f32, uint32_t width, uint32_t height,
+                                  float scale, int rotate180, void* d_rgba8, void* stream);
+int mc_convert_rgba8(mc_context* ctx, const float* rgba_f32, uint32_t width, uint32_t height, float scale,
+                     int rotate180, uint8_t* rgba8);
+
+/* ---- stream / tiling helpers ------------------------------------------------------------------ */
+int mc_context_synchronize(mc_context* ctx);
+/* Number of storage rows in the tile described by (row_begin,row_end,row_block,row_stride). */
+uint32_t mc_tile_rows(uint32_t row_begin, uint32_t row_end, uint32_t row_block, uint32_t row_stride);
+/* Reassembles the storage buffer from n_tiles interleaved tiles laid out back to back, each padded to
+ * tile_rows_padded rows (the layout an RCCL gather of equal-sized tiles leaves on the root): tile t holds
+ * the rows t*row_block + k*n_tiles*row_block + j.  bytes_per_pixel is 16 (vec4 fp32) or 4 (iteration counts). */
+int mc_deinterleave_rows_device_async(mc_context* ctx, const void* d_tiles, uint32_t width, uint32_t height,
+                                      uint32_t n_tiles, uint32_t row_block, uint32_t tile_rows_padded,
+                                      uint32_t bytes_per_pixel, void* d_out, void* stream);
+
+/* ---- single-process multi-GPU render (north_star: row tiles + RCCL gather to rank 0) --------------
+ * Renders the whole image on n_devices GPUs of this node (interleaved row blocks), gathers
+ * the fp32 tiles to device 0 with RCCL over xGMI and copies the assembled storage buffer to
+ * out_rgba_f32 (host, width*height*4 floats).  n_devices = 1 degenerates to the single-GPU path. */
+typedef struct mc_multi mc_multi;
+int mc_multi_create(int n_devices, mc_multi** out);
+int mc_multi_destroy(mc_multi* m);
+int mc_multi_mandelbrot_render(mc_multi* m, const mc_mandelbrot_params* p, float* out_rgba_f32, uint32_t* out_iters);
+int mc_multi_pathtrace_render(mc_multi* m, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
+                              const float* spheres, uint32_t n_spheres, float* out_rgba_f32);
+
+/* ---- device self-tests used by the parity suite (evaluate device functions over arrays) --------- */
+/* fn: 0 mc_sin, 1 mc_cos, 2 mc_log2, 3 mc_exp2, 4 pow(x,0.45), 5 inversesqrt, 6 sqrt, 7 1/x,
+ * 8/9 sin/cos via the fused mc_sincos; fast=1 evaluates the MC_PT_MATH_FAST variants instead. */
+int mc_test_math(mc_context* ctx, int fn, int fast, const float* in, float* out, size_t n);
+/* rand01 (pathTracer.comp:107-110) over n keys (x,y,z) -> 3 floats each. */
+int mc_test_rand01(mc_context* ctx, const uint32_t* xyz, float* out, size_t n);
+/* ds_add/ds_sub/ds_mul/ds_compare (emulateDouble.h.glsl:71-139): op 0..3, n pairs of (hi,lo). */
+int mc_test_ds_op(mc_context* ctx, int op, const float* a, const float* b, float* out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MC_COMPUTE_H_ */

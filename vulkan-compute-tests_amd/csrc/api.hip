@@ -1,0 +1,376 @@
+// C ABI of libmc_compute.so (include/mc_compute.h): context lifecycle, host-buffer entry points,
+// defaults, and the device self-test hooks used by the parity suite.
+#include <cstring>
+
+#include "ds_arith.h"
+#include "mc_internal.h"
+#include "mc_math.h"
+
+namespace mc {
+
+static thread_local std::string g_detail;
+void set_error_detail(const std::string& s) { g_detail = s; }
+
+int DeviceBuffer::reserve(size_t need) {
+    if (need <= bytes && ptr) return MC_OK;
+    if (ptr) {
+        MC_HIP_TRY(hipFree(ptr));
+        ptr = nullptr; bytes = 0;
+    }
+    MC_HIP_TRY(hipMalloc(&ptr, need));
+    bytes = need;
+    return MC_OK;
+}
+void DeviceBuffer::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr; bytes = 0;
+}
+
+// The reference's scene tables — DATA from src/pathtracerApp.h:14-39 (double literals rounded to fp32
+// exactly as `static float planes[] = { .85, ... }` does).
+static const float kDefaultPlanes[6 * 12] = {
+    -1.0f, +0.0f, +0.0f, +2.6f, 0, 0, 0, 0, (float).85, (float).25, (float).25, 1,   // Left
+    +1.0f, +0.0f, +0.0f, +2.6f, 0, 0, 0, 0, (float).25, (float).35, (float).85, 1,   // Right
+    +0.0f, +1.0f, +0.0f, +2.0f, 0, 0, 0, 0, (float).75, (float).75, (float).75, 1,   // Top
+    +0.0f, -1.0f, +0.0f, +2.0f, 0, 0, 0, 0, (float).75, (float).75, (float).75, 1,   // Bottom
+    +0.0f, +0.0f, -1.0f, +2.8f, 0, 0, 0, 0, (float).85, (float).85, (float).25, 1,   // Back
+    +0.0f, +0.0f, +1.0f, +7.9f, 0, 0, 0, 0, (float)0.1, (float)0.7, (float)0.7, 1,   // Front
+};
+static const float kDefaultSpheres[3 * 12] = {
+    (float)-1.3, (float)-1.2, (float)-1.3, (float)0.8, 0, 0, 0, 0, (float).999, (float).999, (float).999, 2,   // mirror
+    (float)1.3,  (float)-1.2, (float)-0.2, (float)0.8, 0, 0, 0, 0, (float).999, (float).999, (float).999, 3,   // glass
+    0, (float)(2 * 0.8), 0, (float)0.2, 100, 100, 100, 0, 0, 0, 0, 1,                                            // light
+};
+
+// ---- device self-test kernels -----------------------------------------------------------------------
+__global__ void test_math_kernel(int fn, int fast, const float* __restrict__ in, float* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = in[i], r = 0.0f;
+    if (!fast) {
+        switch (fn) {
+            case 0: r = dm::mc_sin(x); break;
+            case 1: r = dm::mc_cos(x); break;
+            case 2: r = dm::mc_log2(x); break;
+            case 3: r = dm::mc_exp2(x); break;
+            case 4: r = dm::fpow<false>(x, 0.45f); break;
+            case 5: r = dm::inversesqrt<false>(x); break;
+            case 6: r = dm::fsqrt<false>(x); break;
+            case 7: r = dm::fdiv<false>(1.0f, x); break;
+            case 8: { float s, c; dm::mc_sincos(x, s, c); r = s; } break;
+            case 9: { float s, c; dm::mc_sincos(x, s, c); r = c; } break;
+            default: break;
+        }
+    } else {
+        const float two_pi = 2.0f * 3.141592653589793f;
+        switch (fn) {
+            case 0: case 8: { float s, c; dm::sincos_angle<true>(x, x / two_pi, s, c); r = s; } break;
+            case 1: case 9: { float s, c; dm::sincos_angle<true>(x, x / two_pi, s, c); r = c; } break;
+            case 2: r = __builtin_amdgcn_logf(x); break;
+            case 3: r = __builtin_amdgcn_exp2f(x); break;
+            case 4: r = dm::fpow<true>(x, 0.45f); break;
+            case 5: r = dm::inversesqrt<true>(x); break;
+            case 6: r = dm::fsqrt<true>(x); break;
+            case 7: r = dm::fdiv<true>(1.0f, x); break;
+            default: break;
+        }
+    }
+    out[i] = r;
+}
+
+__global__ void test_rand01_kernel(const uint32_t* __restrict__ xyz, float* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    for (int k = 0; k < 3; k++) {   // pathTracer.comp:107-110
+        uint32_t nx = ((x >> 8) ^ y) * 1103515245u, ny = ((y >> 8) ^ z) * 1103515245u, nz = ((z >> 8) ^ x) * 1103515245u;
+        x = nx; y = ny; z = nz;
+    }
+    const float s = 2.3283064365386963e-10f;
+    out[3 * i] = (float)x * s; out[3 * i + 1] = (float)y * s; out[3 * i + 2] = (float)z * s;
+}
+
+__global__ void test_ds_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                               size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ds2 x{a[2 * i], a[2 * i + 1]}, y{b[2 * i], b[2 * i + 1]}, r{0.0f, 0.0f};
+    switch (op) {
+        case 0: r = ds_add(x, y); break;
+        case 1: r = ds_sub(x, y); break;
+        case 2: r = ds_mul(x, y); break;
+        default: r = ds2{ds_compare(x, y), 0.0f}; break;
+    }
+    out[2 * i] = r.hi; out[2 * i + 1] = r.lo;
+}
+
+}  // namespace mc
+
+using namespace mc;
+
+extern "C" {
+
+int mc_abi_version(void) { return MC_ABI_VERSION; }
+
+const char* mc_error_string(int status) {
+    switch (status) {
+        case MC_OK: return "ok";
+        case MC_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case MC_ERR_NO_DEVICE: return "could not find a HIP device";   // cf. vulkanComputeApp.cpp:78
+        case MC_ERR_HIP: return "HIP runtime error";
+        case MC_ERR_RCCL: return "RCCL error";
+        case MC_ERR_UNSUPPORTED: return "unsupported configuration";
+        case MC_ERR_OUT_OF_MEMORY: return "out of device memory";
+        default: return "unknown error";
+    }
+}
+
+const char* mc_last_error_detail(void) { return g_detail.c_str(); }
+
+int mc_device_count(int* count) {
+    if (!count) return MC_ERR_INVALID_ARGUMENT;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        set_error_detail(std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+        return MC_ERR_NO_DEVICE;
+    }
+    *count = n;
+    return MC_OK;
+}
+
+int mc_context_create(int device, mc_context** out_ctx) {
+    if (!out_ctx) return MC_ERR_INVALID_ARGUMENT;
+    *out_ctx = nullptr;
+    int n = 0;
+    int rc = mc_device_count(&n);
+    if (rc) return rc;
+    if (device < 0 || device >= n) {
+        set_error_detail("device index out of range");
+        return MC_ERR_NO_DEVICE;
+    }
+    MC_HIP_TRY(hipSetDevice(device));
+    mc_context* ctx = new mc_context();
+    ctx->device = device;
+    hipError_t e = hipGetDeviceProperties(&ctx->props, device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        set_error_detail(std::string("context creation: ") + hipGetErrorString(e));
+        delete ctx;
+        return MC_ERR_HIP;
+    }
+    *out_ctx = ctx;
+    return MC_OK;
+}
+
+int mc_context_destroy(mc_context* ctx) {
+    if (!ctx) return MC_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    ctx->lut.release();
+    ctx->scratch_rgba.release();
+    ctx->scratch_iters.release();
+    ctx->scratch_u8.release();
+    delete ctx;
+    return MC_OK;
+}
+
+int mc_context_device_info(mc_context* ctx, char* name, size_t name_len, int* compute_units, int* clock_khz) {
+    if (!ctx) return MC_ERR_INVALID_ARGUMENT;
+    if (name && name_len) {
+        std::strncpy(name, ctx->props.name, name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (compute_units) *compute_units = ctx->props.multiProcessorCount;
+    if (clock_khz) *clock_khz = ctx->props.clockRate;
+    return MC_OK;
+}
+
+int mc_context_synchronize(mc_context* ctx) {
+    if (!ctx) return MC_ERR_INVALID_ARGUMENT;
+    MC_HIP_TRY(hipSetDevice(ctx->device));
+    MC_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MC_OK;
+}
+
+uint32_t mc_tile_rows(uint32_t row_begin, uint32_t row_end, uint32_t row_block, uint32_t row_stride) {
+    return tile_rows(row_begin, row_end, row_stride ? row_block : 0u, row_stride);
+}
+
+int mc_deinterleave_rows_device_async(mc_context* ctx, const void* d_tiles, uint32_t width, uint32_t height,
+                                      uint32_t n_tiles, uint32_t row_block, uint32_t tile_rows_padded,
+                                      uint32_t bytes_per_pixel, void* d_out, void* stream) {
+    if (!ctx) return MC_ERR_INVALID_ARGUMENT;
+    MC_HIP_TRY(hipSetDevice(ctx->device));
+    return deinterleave_rows_launch(ctx, d_tiles, width, height, n_tiles, row_block, tile_rows_padded, bytes_per_pixel,
+                                    d_out, pick_stream(ctx, stream));
+}
+
+// ---- Mandelbrot -------------------------------------------------------------------------------------
+int mc_mandelbrot_default_params(uint32_t width, uint32_t height, mc_mandelbrot_params* p) {
+    if (!p) return MC_ERR_INVALID_ARGUMENT;
+    std::memset(p, 0, sizeof(*p));
+    p->width = width; p->height = height;
+    p->max_iter = 128;                               // mandelbrot.comp:40
+    p->precision = MC_PRECISION_F32;
+    p->centre_x_hi = -0.445f; p->centre_y_hi = 0.0f; // mandelbrot.comp:38
+    p->scale_x_hi = 2.34f; p->scale_y_hi = 2.34f;    // 2.0+1.7*0.2 folds to 2.34f
+    p->k_color[0] = 0.1f; p->k_color[1] = 0.7f; p->k_color[2] = 0.6f; p->k_color[3] = 0.0f;   // mandelbrotApp.h:139
+    p->row_begin = 0; p->row_end = height;
+    return MC_OK;
+}
+
+int mc_mandelbrot_colour_lut(uint32_t max_iter, const float k_color[4], float* lut_f32) {
+    if (!max_iter || !k_color || !lut_f32) return MC_ERR_INVALID_ARGUMENT;
+    mandelbrot_build_lut(max_iter, k_color, lut_f32);
+    return MC_OK;
+}
+
+int mc_mandelbrot_render_device_async(mc_context* ctx, const mc_mandelbrot_params* p, void* d_rgba_f32, void* d_iters,
+                                      void* stream) {
+    if (!ctx) return MC_ERR_INVALID_ARGUMENT;
+    MC_HIP_TRY(hipSetDevice(ctx->device));
+    return mandelbrot_launch(ctx, p, d_rgba_f32, d_iters, pick_stream(ctx, stream));
+}
+
+int mc_mandelbrot_render(mc_context* ctx, const mc_mandelbrot_params* p, float* out_rgba_f32, uint32_t* out_iters) {
+    if (!ctx || !p || (!out_rgba_f32 && !out_iters)) return MC_ERR_INVALID_ARGUMENT;
+    if (p->row_end > p->height || p->row_begin >= p->row_end || !p->width) return MC_ERR_INVALID_ARGUMENT;
+    MC_HIP_TRY(hipSetDevice(ctx->device));
+    const size_t npix = (size_t)mc_tile_rows(p->row_begin, p->row_end, p->row_block, p->row_stride) * p->width;
+    int rc;
+    if (out_rgba_f32 && (rc = ctx->scratch_rgba.reserve(npix * 16))) return rc;
+    if (out_iters && (rc = ctx->scratch_iters.reserve(npix * 4))) return rc;
+    void* d_rgba = out_rgba_f32 ? ctx->scratch_rgba.ptr : nullptr;
+    void* d_it = out_iters ? ctx->scratch_iters.ptr : nullptr;
+    rc = mandelbrot_launch(ctx, p, d_rgba, d_it, ctx->stream);
+    if (rc) return rc;
+    if (out_rgba_f32) MC_HIP_TRY(hipMemcpyAsync(out_rgba_f32, d_rgba, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_iters) MC_HIP_TRY(hipMemcpyAsync(out_iters, d_it, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MC_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MC_OK;
+}
+
+// ---- Path tracer ------------------------------------------------------------------------------------
+int mc_pathtrace_default_params(uint32_t width, uint32_t height, uint32_t spp, mc_pathtrace_params* p) {
+    if (!p) return MC_ERR_INVALID_ARGUMENT;
+    std::memset(p, 0, sizeof(*p));
+    p->width = width; p->height = height; p->spp = spp;
+    p->sample_begin = 0; p->sample_end = spp;
+    p->max_depth = 12;                               // pathTracer.comp:367
+    p->row_begin = 0; p->row_end = height;
+    p->math_mode = MC_PT_MATH_STRICT;
+    return MC_OK;
+}
+
+int mc_pathtrace_default_scene(const float** planes, uint32_t* n_planes, const float** spheres, uint32_t* n_spheres) {
+    if (!planes || !n_planes || !spheres || !n_spheres) return MC_ERR_INVALID_ARGUMENT;
+    *planes = kDefaultPlanes; *n_planes = 6;
+    *spheres = kDefaultSpheres; *n_spheres = 3;
+    return MC_OK;
+}
+
+int mc_pathtrace_render_device_async(mc_context* ctx, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
+                                     const float* spheres, uint32_t n_spheres, void* d_rgba_f32, void* stream) {
+    if (!ctx) return MC_ERR_INVALID_ARGUMENT;
+    MC_HIP_TRY(hipSetDevice(ctx->device));
+    return pathtrace_launch(ctx, p, planes, n_planes, spheres, n_spheres, d_rgba_f32, pick_stream(ctx, stream));
+}
+
+int mc_pathtrace_render(mc_context* ctx, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
+                        const float* spheres, uint32_t n_spheres, float* out_rgba_f32) {
+    if (!ctx || !p || !out_rgba_f32) return MC_ERR_INVALID_ARGUMENT;
+    if (p->row_end > p->height || p->row_begin >= p->row_end || !p->width) return MC_ERR_INVALID_ARGUMENT;
+    MC_HIP_TRY(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)mc_tile_rows(p->row_begin, p->row_end, p->row_block, p->row_stride) * p->width * 16;
+    int rc = ctx->scratch_rgba.reserve(bytes);
+    if (rc) return rc;
+    if (p->sample_begin > 0)   // progressive continuation: the caller's buffer holds the accumulator
+        MC_HIP_TRY(hipMemcpyAsync(ctx->scratch_rgba.ptr, out_rgba_f32, bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = pathtrace_launch(ctx, p, planes, n_planes, spheres, n_spheres, ctx->scratch_rgba.ptr, ctx->stream);
+    if (rc) return rc;
+    MC_HIP_TRY(hipMemcpyAsync(out_rgba_f32, ctx->scratch_rgba.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MC_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MC_OK;
+}
+
+// ---- post-process -----------------------------------------------------------------------------------
+int mc_convert_rgba8_device_async(mc_context* ctx, const void* d_rgba_f32, uint32_t width, uint32_t height, float scale,
+                                  int rotate180, void* d_rgba8, void* stream) {
+    if (!ctx) return MC_ERR_INVALID_ARGUMENT;
+    MC_HIP_TRY(hipSetDevice(ctx->device));
+    return convert_rgba8_launch(ctx, d_rgba_f32, width, height, scale, rotate180, d_rgba8, pick_stream(ctx, stream));
+}
+
+int mc_convert_rgba8(mc_context* ctx, const float* rgba_f32, uint32_t width, uint32_t height, float scale, int rotate180,
+                     uint8_t* rgba8) {
+    if (!ctx || !rgba_f32 || !rgba8 || !width || !height) return MC_ERR_INVALID_ARGUMENT;
+    MC_HIP_TRY(hipSetDevice(ctx->device));
+    const size_t npix = (size_t)width * height;
+    int rc;
+    if ((rc = ctx->scratch_rgba.reserve(npix * 16))) return rc;
+    if ((rc = ctx->scratch_u8.reserve(npix * 4))) return rc;
+    MC_HIP_TRY(hipMemcpyAsync(ctx->scratch_rgba.ptr, rgba_f32, npix * 16, hipMemcpyHostToDevice, ctx->stream));
+    rc = convert_rgba8_launch(ctx, ctx->scratch_rgba.ptr, width, height, scale, rotate180, ctx->scratch_u8.ptr, ctx->stream);
+    if (rc) return rc;
+    MC_HIP_TRY(hipMemcpyAsync(rgba8, ctx->scratch_u8.ptr, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MC_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MC_OK;
+}
+
+// ---- device self-tests ------------------------------------------------------------------------------
+static int run_test(mc_context* ctx, const void* in_a, size_t bytes_a, const void* in_b, size_t bytes_b, void* out,
+                    size_t bytes_out, void (*launch)(void*, void*, void*, size_t, hipStream_t, int, int), size_t n, int p0,
+                    int p1) {
+    MC_HIP_TRY(hipSetDevice(ctx->device));
+    void *da = nullptr, *db = nullptr, *dout = nullptr;
+    MC_HIP_TRY(hipMalloc(&da, bytes_a));
+    if (bytes_b) MC_HIP_TRY(hipMalloc(&db, bytes_b));
+    MC_HIP_TRY(hipMalloc(&dout, bytes_out));
+    MC_HIP_TRY(hipMemcpy(da, in_a, bytes_a, hipMemcpyHostToDevice));
+    if (bytes_b) MC_HIP_TRY(hipMemcpy(db, in_b, bytes_b, hipMemcpyHostToDevice));
+    launch(da, db, dout, n, ctx->stream, p0, p1);
+    MC_HIP_TRY(hipGetLastError());
+    MC_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    MC_HIP_TRY(hipMemcpy(out, dout, bytes_out, hipMemcpyDeviceToHost));
+    (void)hipFree(da);
+    if (db) (void)hipFree(db);
+    (void)hipFree(dout);
+    return MC_OK;
+}
+
+int mc_test_math(mc_context* ctx, int fn, int fast, const float* in, float* out, size_t n) {
+    if (!ctx || !in || !out || !n) return MC_ERR_INVALID_ARGUMENT;
+    return run_test(ctx, in, n * 4, nullptr, 0, out, n * 4,
+                    [](void* a, void*, void* o, size_t n_, hipStream_t s, int fn_, int fast_) {
+                        hipLaunchKernelGGL(test_math_kernel, dim3((unsigned)((n_ + 255) / 256)), dim3(256), 0, s, fn_, fast_,
+                                           (const float*)a, (float*)o, n_);
+                    },
+                    n, fn, fast);
+}
+
+int mc_test_rand01(mc_context* ctx, const uint32_t* xyz, float* out, size_t n) {
+    if (!ctx || !xyz || !out || !n) return MC_ERR_INVALID_ARGUMENT;
+    return run_test(ctx, xyz, n * 12, nullptr, 0, out, n * 12,
+                    [](void* a, void*, void* o, size_t n_, hipStream_t s, int, int) {
+                        hipLaunchKernelGGL(test_rand01_kernel, dim3((unsigned)((n_ + 255) / 256)), dim3(256), 0, s,
+                                           (const uint32_t*)a, (float*)o, n_);
+                    },
+                    n, 0, 0);
+}
+
+int mc_test_ds_op(mc_context* ctx, int op, const float* a, const float* b, float* out, size_t n) {
+    if (!ctx || !a || !b || !out || !n) return MC_ERR_INVALID_ARGUMENT;
+    return run_test(ctx, a, n * 8, b, n * 8, out, n * 8,
+                    [](void* x, void* y, void* o, size_t n_, hipStream_t s, int op_, int) {
+                        hipLaunchKernelGGL(test_ds_kernel, dim3((unsigned)((n_ + 255) / 256)), dim3(256), 0, s, op_,
+                                           (const float*)x, (const float*)y, (float*)o, n_);
+                    },
+                    n, op, 0);
+}
+
+}  // extern "C"

@@ -1,0 +1,208 @@
+// Mandelbrot escape-time kernels for gfx950 (MI355X).
+//
+// Replaces shaders/mandelbrot.comp:21-60 (fp32) and adds the two-float deep-zoom variant composed
+// from the reference's ds_* primitives (shaders/emulateDouble.h.glsl:59-139).
+//
+// Design (MI355X-first, not a translation of the 32x32 Vulkan workgroup):
+//  * one work-item per pixel; a wave64 owns an 8x8 pixel tile (coherent trip counts, and every
+//    128-B output segment of a row is written whole), a 256-thread block owns 16x16 pixels.
+//  * the escape test is a wave ballot (`v_cmp_* sgpr-pair`), not an exec-mask update: the loop body
+//    is straight-line VALU for U iterations and all bookkeeping (OR of the U ballots, "every lane
+//    done" early-out, iteration counter) runs on the scalar unit.  Per-lane iteration counts are
+//    reconstructed from the saved ballots only in the (rare) blocks where some lane escapes.
+//    Interior tiles therefore issue 8 fp32 ops + 1 compare per pixel-iteration.
+//  * unfused IEEE fp32 in GLSL source order: this TU is built with -ffp-contract=off.
+//    zx*zx and zy*zy are computed once per iteration and reused by the magnitude test and the next
+//    update — identical values, so identical results to the literal `dot(z,z)` (mandelbrot.comp:43-44).
+//  * the colour is a host-built (max_iter+1)-entry vec4 LUT: only max_iter+1 distinct
+//    colours exist and GLSL cos() precision is implementation-defined.
+#include <cmath>
+#include <cstring>
+
+#include "ds_arith.h"
+#include "mc_internal.h"
+
+namespace mc {
+
+namespace {
+
+struct MandelArgs {
+    uint32_t W, H, max_iter;
+    uint32_t row_begin, row_end, row_block, row_stride;
+    float cx_hi, cx_lo, cy_hi, cy_lo;
+    float sx_hi, sx_lo, sy_hi, sy_lo;
+    float4* __restrict__ out_rgba;      // tile-local, may be null
+    uint32_t* __restrict__ out_iters;   // tile-local, may be null
+    const float4* __restrict__ lut;     // max_iter+1 entries (null when out_rgba is null)
+};
+
+// ---- per-pixel state machines: step() advances one iteration and reports "escaped now" ----------
+template <bool FMA>
+struct StateF32 {
+    float cx, cy, zx, zy, sx, sy;   // sx = zx*zx, sy = zy*zy of the current z
+    __device__ __forceinline__ void init(uint32_t gx, uint32_t gy, const MandelArgs& a) {
+        float x = (float)gx / (float)a.W;          // mandelbrot.comp:30
+        float y = (float)gy / (float)a.H;          // :31
+        cx = a.cx_hi + (x - 0.5f) * a.sx_hi;       // :38
+        cy = a.cy_hi + (y - 0.5f) * a.sy_hi;
+        zx = zy = sx = sy = 0.0f;
+    }
+    __device__ __forceinline__ bool step() {       // :43-44
+        float nzx, nzy;
+        if (FMA) {   // NON-PARITY diagnostic variant (MC_MANDEL_FMA)
+            nzx = __builtin_fmaf(zx, zx, -sy) + cx;
+            nzy = __builtin_fmaf(2.0f * zx, zy, cy);
+        } else {
+            nzx = (sx - sy) + cx;
+            nzy = ((2.0f * zx) * zy) + cy;
+        }
+        zx = nzx; zy = nzy;
+        sx = zx * zx; sy = zy * zy;
+        return (sx + sy) > 2.0f;
+    }
+};
+
+struct StateDS {
+    ds2 cx, cy, zx, zy, sx, sy;
+    __device__ __forceinline__ void init(uint32_t gx, uint32_t gy, const MandelArgs& a) {
+        float x = (float)gx / (float)a.W;
+        float y = (float)gy / (float)a.H;
+        cx = ds_add(ds2{a.cx_hi, a.cx_lo}, ds_mul(ds_set(x - 0.5f), ds2{a.sx_hi, a.sx_lo}));
+        cy = ds_add(ds2{a.cy_hi, a.cy_lo}, ds_mul(ds_set(y - 0.5f), ds2{a.sy_hi, a.sy_lo}));
+        zx = zy = sx = sy = ds_set(0.0f);
+    }
+    __device__ __forceinline__ bool step() {
+        ds2 zxy = ds_mul(zx, zy);
+        ds2 twoxy = ds2{2.0f * zxy.hi, 2.0f * zxy.lo};   // exact
+        ds2 nzx = ds_add(ds_sub(sx, sy), cx);
+        ds2 nzy = ds_add(twoxy, cy);
+        zx = nzx; zy = nzy;
+        sx = ds_sqr(zx); sy = ds_sqr(zy);
+        return ds_greater(ds_add(sx, sy), ds_set(2.0f));
+    }
+};
+
+// Runs the escape-time loop for the 64 pixels of a wave.  Returns n in [0,max_iter] per lane:
+// the number of iterations that did not escape (mandelbrot.comp:40-46).
+template <class State, int U>
+__device__ __forceinline__ uint32_t escape_time(State& st, uint32_t max_iter, bool valid) {
+    const uint32_t lane = __lane_id();
+    const uint64_t lanebit = 1ull << lane;
+    uint64_t done = ~__ballot(valid);   // lanes outside the image never hold the wave
+    uint32_t n = max_iter;
+    uint32_t i = 0;
+    for (; i + U <= max_iter; i += U) {
+        uint64_t b[U];
+        uint64_t any = 0;
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            b[k] = __ballot(st.step());
+            any |= b[k];
+        }
+        uint64_t newly = any & ~done;
+        if (newly) {   // wave-uniform: some lane escaped for the first time in this block
+#pragma unroll
+            for (int k = U - 1; k >= 0; k--)
+                if (b[k] & ~done & lanebit) n = i + k;
+            done |= any;
+            if (done == ~0ull) return n;
+        }
+    }
+    for (; i < max_iter; i++) {   // tail: max_iter % U iterations
+        uint64_t b = __ballot(st.step());
+        uint64_t newly = b & ~done;
+        if (newly) {
+            if (newly & lanebit) n = i;
+            done |= b;
+            if (done == ~0ull) return n;
+        }
+    }
+    return n;
+}
+
+template <class State, int U>
+__global__ void __launch_bounds__(256) mandelbrot_kernel(MandelArgs a) {
+    // block = 16x16 pixels, wave = 8x8 tile, lane = (lx, ly) inside the tile
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t gx = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t ty = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);   // tile-local row
+    const uint32_t gy = tile_row_to_storage(ty, a.row_begin, a.row_block, a.row_stride);
+    const bool valid = gx < a.W && gy < a.row_end;                            // mandelbrot.comp:27-28
+    State st;
+    st.init(valid ? gx : 0u, valid ? gy : 0u, a);
+    uint32_t n = escape_time<State, U>(st, a.max_iter, valid);
+    if (valid) {
+        size_t idx = (size_t)ty * a.W + gx;                                    // :59 (row-major, tile-local)
+        if (a.out_iters) a.out_iters[idx] = n;
+        if (a.out_rgba) a.out_rgba[idx] = a.lut[n];
+    }
+}
+
+}  // namespace
+
+// colour(n) = d + e*cos(6.28318*(f*t+g)), t = n/M — mandelbrot.comp:50-56, evaluated in fp32 in source
+// order on the host (d = kColor.rgb, mandelbrotApp.h:139-141).  alpha = 1.0.
+void mandelbrot_build_lut(uint32_t max_iter, const float k_color[4], float* lut) {
+    const float e[3] = {-0.2f, -0.3f, -0.5f};
+    const float f[3] = {2.1f, 2.0f, 3.0f};
+    const float g[3] = {0.0f, 0.1f, 0.0f};
+    for (uint32_t n = 0; n <= max_iter; n++) {
+        float t = (float)n / (float)max_iter;
+        for (int c = 0; c < 3; c++) {
+            float arg = 6.28318f * (f[c] * t + g[c]);
+            lut[4 * (size_t)n + c] = k_color[c] + e[c] * cosf(arg);
+        }
+        lut[4 * (size_t)n + 3] = 1.0f;
+    }
+}
+
+static int ensure_lut(mc_context* ctx, const mc_mandelbrot_params* p, hipStream_t s) {
+    if (ctx->lut_max_iter == p->max_iter && std::memcmp(ctx->lut_kcolor, p->k_color, sizeof(float) * 4) == 0 && ctx->lut.ptr)
+        return MC_OK;
+    size_t bytes = ((size_t)p->max_iter + 1) * 4 * sizeof(float);
+    std::vector<float> host(((size_t)p->max_iter + 1) * 4);
+    mandelbrot_build_lut(p->max_iter, p->k_color, host.data());
+    // a previous launch may still be reading the old table on another stream: drain before replacing it
+    MC_HIP_TRY(hipDeviceSynchronize());
+    int rc = ctx->lut.reserve(bytes);
+    if (rc) return rc;
+    MC_HIP_TRY(hipMemcpyAsync(ctx->lut.ptr, host.data(), bytes, hipMemcpyHostToDevice, s));
+    MC_HIP_TRY(hipStreamSynchronize(s));   // host vector goes out of scope
+    ctx->lut_max_iter = p->max_iter;
+    std::memcpy(ctx->lut_kcolor, p->k_color, sizeof(float) * 4);
+    return MC_OK;
+}
+
+int mandelbrot_launch(mc_context* ctx, const mc_mandelbrot_params* p, void* d_rgba, void* d_iters, hipStream_t s) {
+    if (!ctx || !p || (!d_rgba && !d_iters)) return MC_ERR_INVALID_ARGUMENT;
+    if (!p->width || !p->height || !p->max_iter || p->row_end > p->height || p->row_begin >= p->row_end)
+        return MC_ERR_INVALID_ARGUMENT;
+    if (p->precision != MC_PRECISION_F32 && p->precision != MC_PRECISION_DS) return MC_ERR_INVALID_ARGUMENT;
+    if (p->row_stride && (!p->row_block || p->row_block > p->row_stride)) return MC_ERR_INVALID_ARGUMENT;
+    if (d_rgba) {
+        int rc = ensure_lut(ctx, p, s);
+        if (rc) return rc;
+    }
+    MandelArgs a;
+    a.W = p->width; a.H = p->height; a.max_iter = p->max_iter;
+    a.row_begin = p->row_begin; a.row_end = p->row_end;
+    a.row_block = p->row_stride ? p->row_block : 0u; a.row_stride = p->row_stride;
+    a.cx_hi = p->centre_x_hi; a.cx_lo = p->centre_x_lo; a.cy_hi = p->centre_y_hi; a.cy_lo = p->centre_y_lo;
+    a.sx_hi = p->scale_x_hi; a.sx_lo = p->scale_x_lo; a.sy_hi = p->scale_y_hi; a.sy_lo = p->scale_y_lo;
+    a.out_rgba = (float4*)d_rgba;
+    a.out_iters = (uint32_t*)d_iters;
+    a.lut = d_rgba ? (const float4*)ctx->lut.ptr : nullptr;
+    const uint32_t rows = tile_rows(p->row_begin, p->row_end, a.row_block, a.row_stride);
+    dim3 grid((p->width + 15u) / 16u, (rows + 15u) / 16u), block(256);
+    if (p->precision == MC_PRECISION_DS) {
+        hipLaunchKernelGGL((mandelbrot_kernel<StateDS, 2>), grid, block, 0, s, a);
+    } else if (p->flags & MC_MANDEL_FMA) {
+        hipLaunchKernelGGL((mandelbrot_kernel<StateF32<true>, 8>), grid, block, 0, s, a);
+    } else {
+        hipLaunchKernelGGL((mandelbrot_kernel<StateF32<false>, 8>), grid, block, 0, s, a);
+    }
+    MC_HIP_TRY(hipGetLastError());
+    return MC_OK;
+}
+
+}  // namespace mc

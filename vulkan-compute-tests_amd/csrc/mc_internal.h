@@ -1,0 +1,78 @@
+// Internal declarations shared by the translation units of libmc_compute.so (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/mc_compute.h"
+
+namespace mc {
+
+void set_error_detail(const std::string& s);
+
+#define MC_HIP_TRY(expr)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            ::mc::set_error_detail(std::string(#expr) + ": " + hipGetErrorString(e_));                \
+            return e_ == hipErrorOutOfMemory ? MC_ERR_OUT_OF_MEMORY : MC_ERR_HIP;                     \
+        }                                                                                             \
+    } while (0)
+
+// Device-resident scratch that grows on demand and is reused between calls.
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t need);
+    void release();
+};
+
+}  // namespace mc
+
+struct mc_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t props{};
+    // colour LUT cache (Mandelbrot): rebuilt when (max_iter, k_color) changes
+    mc::DeviceBuffer lut;
+    uint32_t lut_max_iter = 0xffffffffu;
+    float lut_kcolor[4] = {0, 0, 0, 0};
+    // scratch for the host-buffer entry points
+    mc::DeviceBuffer scratch_rgba, scratch_iters, scratch_u8;
+};
+
+namespace mc {
+
+// mandelbrot.hip
+int mandelbrot_launch(mc_context* ctx, const mc_mandelbrot_params* p, void* d_rgba, void* d_iters, hipStream_t s);
+void mandelbrot_build_lut(uint32_t max_iter, const float k_color[4], float* lut);
+// pathtrace.hip
+int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
+                     const float* spheres, uint32_t n_spheres, void* d_rgba, hipStream_t s);
+// postprocess.hip
+int convert_rgba8_launch(mc_context* ctx, const void* d_rgba_f32, uint32_t W, uint32_t H, float scale, int rotate180,
+                         void* d_rgba8, hipStream_t s);
+int deinterleave_rows_launch(mc_context* ctx, const void* d_tiles, uint32_t W, uint32_t H, uint32_t n_tiles, uint32_t B,
+                             uint32_t tile_rows_padded, uint32_t bytes_per_pixel, void* d_out, hipStream_t s);
+
+// Interleaved row-block tiling (include/mc_compute.h: row_block,row_stride).  Tile-local row ty maps to
+// storage row row_begin + (ty / B) * stride + ty % B; B == 0 means contiguous.
+__host__ __device__ inline uint32_t tile_row_to_storage(uint32_t ty, uint32_t row_begin, uint32_t B, uint32_t stride) {
+    if (B == 0u) return row_begin + ty;
+    uint32_t k = ty / B;
+    return row_begin + k * stride + (ty - k * B);
+}
+inline uint32_t tile_rows(uint32_t row_begin, uint32_t row_end, uint32_t B, uint32_t stride) {
+    if (row_begin >= row_end) return 0;
+    if (B == 0u || stride == 0u) return row_end - row_begin;
+    uint32_t span = row_end - row_begin;
+    uint32_t full = span / stride, rem = span - full * stride;
+    return full * B + (rem < B ? rem : B);
+}
+
+inline hipStream_t pick_stream(mc_context* ctx, void* stream) { return stream ? (hipStream_t)stream : ctx->stream; }
+
+}  // namespace mc

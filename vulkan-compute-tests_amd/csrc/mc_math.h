@@ -1,0 +1,149 @@
+// Device math for the path tracer, in two flavours selected at compile time by `Fast`:
+//
+//  strict (Fast = false): every operation is one IEEE-754 fp32 operation (correctly rounded +,-,*,/,
+//     sqrt, fma) in a FIXED order, so results are bit-identical to a CPU evaluating the same sequence
+//     (DESIGN.md §"mc math").  GLSL leaves sin/cos/pow/inversesqrt precision implementation-defined
+//     (SURVEY.md H5); these algorithms are this build's canonical choice for them:
+//        inversesqrt(x) := 1.0f / sqrt(x)
+//        sin/cos        := Cody–Waite pi/2 reduction + cephes sinf/cosf kernels (fmaf form)
+//        pow(x, y)      := exp2(y * log2(x)) with cephes-style logf/exp2f kernels (fmaf form)
+//  fast (Fast = true): gfx950 hardware approximations — v_rcp_f32, v_rsq_f32, v_sqrt_f32,
+//     v_sin_f32/v_cos_f32 (input in revolutions), v_exp_f32/v_log_f32.  ~1 ulp each; toleranced parity.
+//
+// Requires -ffp-contract=off (explicit __builtin_fmaf calls are the only fused operations).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mc {
+namespace dm {
+
+__device__ __forceinline__ float as_float(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t as_uint(float f) { return __float_as_uint(f); }
+
+// ---- IEEE primitives ------------------------------------------------------------------------------
+// hipcc's default for HIP is correctly-rounded fp32 divide and sqrt (-fhip-fp32-correctly-rounded-divide-sqrt);
+// the parity tests (tests/test_device_math.py) verify both against the host bit for bit.
+__device__ __forceinline__ float ieee_div(float a, float b) { return a / b; }
+__device__ __forceinline__ float ieee_sqrt(float a) { return __builtin_sqrtf(a); }
+
+template <bool Fast> __device__ __forceinline__ float fdiv(float a, float b) {
+    if (Fast) return a * __builtin_amdgcn_rcpf(b);
+    return ieee_div(a, b);
+}
+template <bool Fast> __device__ __forceinline__ float fsqrt(float a) {
+    if (Fast) return __builtin_amdgcn_sqrtf(a);
+    return ieee_sqrt(a);
+}
+template <bool Fast> __device__ __forceinline__ float inversesqrt(float a) {
+    if (Fast) return __builtin_amdgcn_rsqf(a);
+    return ieee_div(1.0f, ieee_sqrt(a));
+}
+
+// ---- strict sin / cos ------------------------------------------------------------------------------
+__device__ __forceinline__ void sincos_reduce(float x, float& r, int& k) {
+    const float TWO_OVER_PI = 0.636619772367581343f;
+    const float PIO2_HI = 1.5703125f;
+    const float PIO2_MID = 4.837512969970703125e-4f;
+    const float PIO2_LO = 7.54978995489188216e-8f;
+    float q = __builtin_rintf(x * TWO_OVER_PI);   // v_rndne_f32 (round to nearest even)
+    r = __builtin_fmaf(q, -PIO2_HI, x);
+    r = __builtin_fmaf(q, -PIO2_MID, r);
+    r = __builtin_fmaf(q, -PIO2_LO, r);
+    k = (int)q;
+}
+__device__ __forceinline__ float sin_kernel(float r) {
+    float z = r * r;
+    float p = __builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    p = __builtin_fmaf(p, z, -1.6666654611e-1f);
+    return __builtin_fmaf(p * z, r, r);
+}
+__device__ __forceinline__ float cos_kernel(float r) {
+    float z = r * r;
+    float p = __builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    p = __builtin_fmaf(p, z, 4.166664568298827e-2f);
+    float t = __builtin_fmaf(-0.5f, z, 1.0f);
+    return __builtin_fmaf(p * z, z, t);
+}
+__device__ __forceinline__ float mc_sin(float x) {
+    float r; int k; sincos_reduce(x, r, k);
+    float s = (k & 1) ? cos_kernel(r) : sin_kernel(r);
+    return (k & 2) ? -s : s;
+}
+__device__ __forceinline__ float mc_cos(float x) {
+    float r; int k; sincos_reduce(x, r, k);
+    float c = (k & 1) ? sin_kernel(r) : cos_kernel(r);
+    return ((k + 1) & 2) ? -c : c;
+}
+// both at once (shares the reduction and both kernels; bit-identical to mc_sin/mc_cos)
+__device__ __forceinline__ void mc_sincos(float x, float& s, float& c) {
+    float r; int k; sincos_reduce(x, r, k);
+    float sk = sin_kernel(r), ck = cos_kernel(r);
+    float sv = (k & 1) ? ck : sk;
+    float cv = (k & 1) ? sk : ck;
+    s = (k & 2) ? -sv : sv;
+    c = ((k + 1) & 2) ? -cv : cv;
+}
+
+// sin/cos of angle = two_pi_f32 * u where `angle` is the already-rounded fp32 product the shader
+// computes (pathTracer.comp:412,426) and `u` the random number it came from.
+template <bool Fast> __device__ __forceinline__ void sincos_angle(float angle, float u, float& s, float& c) {
+    if (Fast) {
+        // v_sin_f32 / v_cos_f32 take revolutions: sin(2*pi*u).  u in [0,1].
+        s = __builtin_amdgcn_sinf(u);
+        c = __builtin_amdgcn_cosf(u);
+    } else {
+        mc_sincos(angle, s, c);
+    }
+}
+
+// ---- strict log2 / exp2 / pow ------------------------------------------------------------------------
+__device__ __forceinline__ float mc_log2(float x) {
+    if (x == 0.0f) return -__builtin_inff();
+    int e_adj = 0;
+    if (x < 1.17549435e-38f) { x = x * 16777216.0f; e_adj = -24; }
+    uint32_t u = as_uint(x);
+    int e = (int)(u >> 23) - 127;
+    float m = as_float((u & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356237f) { m = m * 0.5f; e += 1; }
+    float t = m - 1.0f;
+    float z = t * t;
+    float p = __builtin_fmaf(7.0376836292e-2f, t, -1.1514610310e-1f);
+    p = __builtin_fmaf(p, t, 1.1676998740e-1f);
+    p = __builtin_fmaf(p, t, -1.2420140846e-1f);
+    p = __builtin_fmaf(p, t, 1.4249322787e-1f);
+    p = __builtin_fmaf(p, t, -1.6668057665e-1f);
+    p = __builtin_fmaf(p, t, 2.0000714765e-1f);
+    p = __builtin_fmaf(p, t, -2.4999993993e-1f);
+    p = __builtin_fmaf(p, t, 3.3333331174e-1f);
+    float ln = __builtin_fmaf(t * z, p, __builtin_fmaf(-0.5f, z, t));
+    const float LOG2E_HI = 1.44269502162933349609375f;
+    const float LOG2E_LO = 1.92596299112661746e-8f;
+    float r = __builtin_fmaf(ln, LOG2E_LO, 0.0f);
+    r = __builtin_fmaf(ln, LOG2E_HI, r);
+    return r + (float)(e + e_adj);
+}
+__device__ __forceinline__ float mc_exp2(float y) {
+    if (!(y >= -125.0f)) return 0.0f;
+    if (y > 127.0f) return __builtin_inff();
+    float n = __builtin_rintf(y);
+    float f = y - n;
+    float p = __builtin_fmaf(1.535336188319500e-4f, f, 1.339887440266574e-3f);
+    p = __builtin_fmaf(p, f, 9.618437357674640e-3f);
+    p = __builtin_fmaf(p, f, 5.550357105498874e-2f);
+    p = __builtin_fmaf(p, f, 2.402264791363012e-1f);
+    p = __builtin_fmaf(p, f, 6.931472028550421e-1f);
+    p = __builtin_fmaf(p, f, 1.0f);
+    int e = (int)n + 127;
+    return p * as_float((uint32_t)e << 23);
+}
+template <bool Fast> __device__ __forceinline__ float fpow(float x, float y) {
+    if (Fast) return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));   // v_exp_f32(y * v_log_f32(x))
+    return mc_exp2(y * mc_log2(x));
+}
+
+// GLSL max/min (NaN behaviour differs from v_max_f32): max(x,y) = x<y ? y : x ; min(x,y) = y<x ? y : x
+__device__ __forceinline__ float gmax(float x, float y) { return (x < y) ? y : x; }
+__device__ __forceinline__ float gmin(float x, float y) { return (y < x) ? y : x; }
+
+}  // namespace dm
+}  // namespace mc

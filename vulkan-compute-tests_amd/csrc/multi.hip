@@ -1,0 +1,204 @@
+// Single-process multi-GPU render: interleaved row blocks per GPU, one RCCL gather of the fp32 tiles to
+// device 0 over xGMI, de-interleave on device 0, one D2H copy (north_star).
+//
+// The reference is single-device (vulkanComputeApp.cpp:163 takes devices[0]); this is the scale-out
+// the north_star adds.  Every pixel is independent and keyed by its absolute coordinates
+// (pathTracer.comp:357,393), so a rank rendering rows with the GLOBAL (gx, gy, W, H) produces the
+// same bits as the single-GPU run: N-GPU output must memcmp-equal the 1-GPU output.  Samples are
+// never split across GPUs (the fp32 accumulation order is part of the contract).
+//
+// A gather to one root on the fully connected 8-GPU xGMI mesh uses the root's 7 inbound links
+// concurrently; tiles are 20-80 MB/rank, i.e. well under a millisecond next to >=100 ms renders.
+#include <rccl/rccl.h>
+
+#include <cstdlib>
+#include <cstring>
+
+#include "mc_internal.h"
+
+struct mc_multi {
+    int n = 0;
+    std::vector<mc_context*> ctx;
+    std::vector<ncclComm_t> comms;
+    std::vector<mc::DeviceBuffer> tile_rgba, tile_iters;
+    mc::DeviceBuffer gather_rgba, gather_iters, full_rgba, full_iters;   // on device 0
+    bool use_rccl = false;
+};
+
+namespace mc {
+
+#define MC_NCCL_TRY(expr)                                                                       \
+    do {                                                                                        \
+        ncclResult_t r_ = (expr);                                                               \
+        if (r_ != ncclSuccess) {                                                                \
+            ::mc::set_error_detail(std::string(#expr) + ": " + ncclGetErrorString(r_));         \
+            return MC_ERR_RCCL;                                                                 \
+        }                                                                                       \
+    } while (0)
+
+constexpr uint32_t kRowBlock = 16;   // rows per interleave block = the kernels' 16-row thread-block tile
+
+// Gathers equal-sized tiles (count elements of `type` per rank) to device 0 and de-interleaves them.
+static int gather_and_assemble(mc_multi* m, std::vector<DeviceBuffer>& tiles, DeviceBuffer& gathered, DeviceBuffer& full,
+                               uint32_t W, uint32_t H, uint32_t tile_rows_padded, uint32_t bpp) {
+    const size_t tile_bytes = (size_t)tile_rows_padded * W * bpp;
+    mc_context* c0 = m->ctx[0];
+    MC_HIP_TRY(hipSetDevice(c0->device));
+    int rc;
+    if ((rc = gathered.reserve(tile_bytes * m->n))) return rc;
+    if ((rc = full.reserve((size_t)W * H * bpp))) return rc;
+    if (m->use_rccl) {
+        MC_NCCL_TRY(ncclGroupStart());
+        for (int i = 0; i < m->n; i++) {
+            // ncclGather is an RCCL extension (rccl.h); bytes are moved as ncclUint8 so vec4 and u32 tiles share the path
+            ncclResult_t r = ncclGather(tiles[i].ptr, i == 0 ? gathered.ptr : nullptr, tile_bytes, ncclUint8, 0, m->comms[i],
+                                        m->ctx[i]->stream);
+            if (r != ncclSuccess) {
+                (void)ncclGroupEnd();
+                set_error_detail(std::string("ncclGather: ") + ncclGetErrorString(r));
+                return MC_ERR_RCCL;
+            }
+        }
+        MC_NCCL_TRY(ncclGroupEnd());
+    } else {
+        // n == 1 without a communicator: the "gather" is the tile itself
+        MC_HIP_TRY(hipMemcpyAsync(gathered.ptr, tiles[0].ptr, tile_bytes, hipMemcpyDeviceToDevice, c0->stream));
+    }
+    MC_HIP_TRY(hipSetDevice(c0->device));
+    return deinterleave_rows_launch(c0, gathered.ptr, W, H, (uint32_t)m->n, kRowBlock, tile_rows_padded, bpp, full.ptr,
+                                    c0->stream);
+}
+
+static uint32_t padded_tile_rows(uint32_t H, int n) {
+    // rank 0 always owns the most rows
+    return tile_rows(0, H, kRowBlock, kRowBlock * (uint32_t)n);
+}
+
+}  // namespace mc
+
+using namespace mc;
+
+extern "C" {
+
+int mc_multi_create(int n_devices, mc_multi** out) {
+    if (!out || n_devices < 1) return MC_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int have = 0;
+    int rc = mc_device_count(&have);
+    if (rc) return rc;
+    if (n_devices > have) {
+        set_error_detail("fewer HIP devices than requested");
+        return MC_ERR_NO_DEVICE;
+    }
+    mc_multi* m = new mc_multi();
+    m->n = n_devices;
+    m->ctx.resize(n_devices, nullptr);
+    m->tile_rgba.resize(n_devices);
+    m->tile_iters.resize(n_devices);
+    for (int i = 0; i < n_devices; i++) {
+        rc = mc_context_create(i, &m->ctx[i]);
+        if (rc) { mc_multi_destroy(m); return rc; }
+    }
+    const char* force = std::getenv("MC_MULTI_FORCE_RCCL");
+    m->use_rccl = n_devices > 1 || (force && force[0] == '1');
+    if (m->use_rccl) {
+        std::vector<int> devs(n_devices);
+        for (int i = 0; i < n_devices; i++) devs[i] = i;
+        m->comms.resize(n_devices);
+        ncclResult_t r = ncclCommInitAll(m->comms.data(), n_devices, devs.data());
+        if (r != ncclSuccess) {
+            m->comms.clear();
+            set_error_detail(std::string("ncclCommInitAll: ") + ncclGetErrorString(r));
+            mc_multi_destroy(m);
+            return MC_ERR_RCCL;
+        }
+    }
+    *out = m;
+    return MC_OK;
+}
+
+int mc_multi_destroy(mc_multi* m) {
+    if (!m) return MC_OK;
+    for (size_t i = 0; i < m->comms.size(); i++)
+        if (m->comms[i]) (void)ncclCommDestroy(m->comms[i]);
+    for (int i = 0; i < m->n; i++) {
+        if (!m->ctx[i]) continue;
+        (void)hipSetDevice(m->ctx[i]->device);
+        m->tile_rgba[i].release();
+        m->tile_iters[i].release();
+    }
+    if (m->n && m->ctx[0]) {
+        (void)hipSetDevice(m->ctx[0]->device);
+        m->gather_rgba.release(); m->gather_iters.release(); m->full_rgba.release(); m->full_iters.release();
+    }
+    for (int i = 0; i < m->n; i++) mc_context_destroy(m->ctx[i]);
+    delete m;
+    return MC_OK;
+}
+
+int mc_multi_mandelbrot_render(mc_multi* m, const mc_mandelbrot_params* p, float* out_rgba_f32, uint32_t* out_iters) {
+    if (!m || !p || (!out_rgba_f32 && !out_iters)) return MC_ERR_INVALID_ARGUMENT;
+    if (p->row_begin != 0 || p->row_end != p->height || p->row_stride) return MC_ERR_INVALID_ARGUMENT;   // whole image only
+    if ((p->width % 4u) != 0 && out_iters && m->n > 1) return MC_ERR_UNSUPPORTED;   // 16-B row granules for the u32 plane
+    const uint32_t W = p->width, H = p->height;
+    const uint32_t padded = padded_tile_rows(H, m->n);
+    int rc;
+    for (int i = 0; i < m->n; i++) {
+        mc_context* c = m->ctx[i];
+        MC_HIP_TRY(hipSetDevice(c->device));
+        if (out_rgba_f32 && (rc = m->tile_rgba[i].reserve((size_t)padded * W * 16))) return rc;
+        if (out_iters && (rc = m->tile_iters[i].reserve((size_t)padded * W * 4))) return rc;
+        mc_mandelbrot_params q = *p;
+        q.row_begin = (uint32_t)i * kRowBlock; q.row_end = H;
+        q.row_block = kRowBlock; q.row_stride = kRowBlock * (uint32_t)m->n;
+        if (q.row_begin >= H) continue;   // more GPUs than row blocks
+        rc = mandelbrot_launch(c, &q, out_rgba_f32 ? m->tile_rgba[i].ptr : nullptr, out_iters ? m->tile_iters[i].ptr : nullptr,
+                               c->stream);
+        if (rc) return rc;
+    }
+    mc_context* c0 = m->ctx[0];
+    if (out_rgba_f32) {
+        if ((rc = gather_and_assemble(m, m->tile_rgba, m->gather_rgba, m->full_rgba, W, H, padded, 16))) return rc;
+        MC_HIP_TRY(hipMemcpyAsync(out_rgba_f32, m->full_rgba.ptr, (size_t)W * H * 16, hipMemcpyDeviceToHost, c0->stream));
+    }
+    if (out_iters) {
+        if ((rc = gather_and_assemble(m, m->tile_iters, m->gather_iters, m->full_iters, W, H, padded, 4))) return rc;
+        MC_HIP_TRY(hipMemcpyAsync(out_iters, m->full_iters.ptr, (size_t)W * H * 4, hipMemcpyDeviceToHost, c0->stream));
+    }
+    for (int i = 0; i < m->n; i++) {
+        MC_HIP_TRY(hipSetDevice(m->ctx[i]->device));
+        MC_HIP_TRY(hipStreamSynchronize(m->ctx[i]->stream));
+    }
+    return MC_OK;
+}
+
+int mc_multi_pathtrace_render(mc_multi* m, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
+                              const float* spheres, uint32_t n_spheres, float* out_rgba_f32) {
+    if (!m || !p || !out_rgba_f32) return MC_ERR_INVALID_ARGUMENT;
+    if (p->row_begin != 0 || p->row_end != p->height || p->row_stride) return MC_ERR_INVALID_ARGUMENT;
+    if (p->sample_begin != 0) return MC_ERR_UNSUPPORTED;   // progressive continuation: single-GPU entry points
+    const uint32_t W = p->width, H = p->height;
+    const uint32_t padded = padded_tile_rows(H, m->n);
+    int rc;
+    for (int i = 0; i < m->n; i++) {
+        mc_context* c = m->ctx[i];
+        MC_HIP_TRY(hipSetDevice(c->device));
+        if ((rc = m->tile_rgba[i].reserve((size_t)padded * W * 16))) return rc;
+        mc_pathtrace_params q = *p;
+        q.row_begin = (uint32_t)i * kRowBlock; q.row_end = H;
+        q.row_block = kRowBlock; q.row_stride = kRowBlock * (uint32_t)m->n;
+        if (q.row_begin >= H) continue;
+        rc = pathtrace_launch(c, &q, planes, n_planes, spheres, n_spheres, m->tile_rgba[i].ptr, c->stream);
+        if (rc) return rc;
+    }
+    if ((rc = gather_and_assemble(m, m->tile_rgba, m->gather_rgba, m->full_rgba, W, H, padded, 16))) return rc;
+    mc_context* c0 = m->ctx[0];
+    MC_HIP_TRY(hipMemcpyAsync(out_rgba_f32, m->full_rgba.ptr, (size_t)W * H * 16, hipMemcpyDeviceToHost, c0->stream));
+    for (int i = 0; i < m->n; i++) {
+        MC_HIP_TRY(hipSetDevice(m->ctx[i]->device));
+        MC_HIP_TRY(hipStreamSynchronize(m->ctx[i]->stream));
+    }
+    return MC_OK;
+}
+
+}  // extern "C"

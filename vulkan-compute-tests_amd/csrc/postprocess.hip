@@ -1,0 +1,88 @@
+// Storage-buffer -> RGBA8 conversion on the GPU.
+//
+// Replaces the scalar host loops of getRenderedImage (src/mandelbrotApp.h:149-170 with scale 255,
+// src/pathtracerApp.h:202-223 with scale 1) and the in-place 180-degree rotation of
+// saveRenderedImage (src/pathtracerApp.h:236-243), so only 4 B/pixel instead of 16 B/pixel cross
+// PCIe.  HBM-bound: 16 B read + 4 B written per pixel, one pixel per lane (float4 load, u32 store).
+//
+// u8 = static_cast<uint8_t>(scale * c) has undefined behaviour out of range in C++; the reference
+// binary on x86-64 executes cvttss2si (truncate to int32; "indefinite" 0x80000000 when out of range
+// or NaN) and keeps the low byte.  That behaviour is reproduced explicitly.
+#include "mc_internal.h"
+
+namespace mc {
+
+namespace {
+
+__device__ __forceinline__ uint32_t x86_float_to_u8(float v) {
+    // in-range: truncate toward zero; out of int32 range or NaN: 0x80000000 -> low byte 0
+    bool in_range = (v > -2147483648.0f) && (v < 2147483648.0f);
+    int32_t i = in_range ? (int32_t)v : (int32_t)0x80000000;
+    return (uint32_t)i & 0xffu;
+}
+
+__global__ void __launch_bounds__(256) convert_rgba8_kernel(const float4* __restrict__ src, uint32_t* __restrict__ dst,
+                                                            uint32_t W, uint32_t H, float scale, int rotate180) {
+    const size_t npix = (size_t)W * H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+        size_t j = i;
+        if (rotate180) {
+            // pathtracerApp.h:237-243 swaps (x,y) <-> (W-1-x, H-1-y) for x < W/2 only: with odd W the
+            // middle column stays in place (latent reference behaviour, kept).
+            uint32_t y = (uint32_t)(i / W), x = (uint32_t)(i - (size_t)y * W);
+            bool middle = (W & 1u) && x == W / 2u;
+            if (!middle) j = (size_t)(H - 1u - y) * W + (W - 1u - x);
+        }
+        float4 c = src[j];
+        uint32_t r = x86_float_to_u8(scale * c.x), g = x86_float_to_u8(scale * c.y), b = x86_float_to_u8(scale * c.z);
+        dst[i] = r | (g << 8) | (b << 16) | 0xff000000u;
+    }
+}
+
+// Rebuilds the storage buffer from interleaved tiles (the layout an RCCL gather leaves on the root):
+// storage row r = (k*n_tiles + t)*B + j  <-  tile t, tile row k*B + j.  16-B granules, HBM-bound.
+__global__ void __launch_bounds__(256) deinterleave_rows_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                                uint32_t row_granules, uint32_t H, uint32_t n_tiles,
+                                                                uint32_t B, uint32_t tile_rows_padded) {
+    const size_t total = (size_t)row_granules * H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t r = (uint32_t)(i / row_granules), g = (uint32_t)(i - (size_t)r * row_granules);
+        uint32_t blk = r / B, j = r - blk * B;
+        uint32_t t = blk % n_tiles, k = blk / n_tiles;
+        size_t srow = (size_t)t * tile_rows_padded + (size_t)k * B + j;
+        dst[i] = src[srow * row_granules + g];
+    }
+}
+
+}  // namespace
+
+int deinterleave_rows_launch(mc_context* ctx, const void* d_tiles, uint32_t W, uint32_t H, uint32_t n_tiles, uint32_t B,
+                             uint32_t tile_rows_padded, uint32_t bytes_per_pixel, void* d_out, hipStream_t s) {
+    if (!ctx || !d_tiles || !d_out || !W || !H || !n_tiles || !B) return MC_ERR_INVALID_ARGUMENT;
+    size_t row_bytes = (size_t)W * bytes_per_pixel;
+    if ((bytes_per_pixel != 16 && bytes_per_pixel != 4) || (row_bytes % 16) != 0) return MC_ERR_INVALID_ARGUMENT;
+    uint32_t row_granules = (uint32_t)(row_bytes / 16);
+    size_t total = (size_t)row_granules * H;
+    uint32_t blocks = (uint32_t)((total + 255) / 256);
+    uint32_t cap = (uint32_t)ctx->props.multiProcessorCount * 8u;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(deinterleave_rows_kernel, dim3(blocks), dim3(256), 0, s, (const uint4*)d_tiles, (uint4*)d_out,
+                       row_granules, H, n_tiles, B, tile_rows_padded);
+    MC_HIP_TRY(hipGetLastError());
+    return MC_OK;
+}
+
+int convert_rgba8_launch(mc_context* ctx, const void* d_rgba_f32, uint32_t W, uint32_t H, float scale, int rotate180,
+                         void* d_rgba8, hipStream_t s) {
+    if (!ctx || !d_rgba_f32 || !d_rgba8 || !W || !H) return MC_ERR_INVALID_ARGUMENT;
+    size_t npix = (size_t)W * H;
+    uint32_t blocks = (uint32_t)((npix + 255) / 256);
+    uint32_t cap = (uint32_t)ctx->props.multiProcessorCount * 8u;   // grid-stride beyond 8 blocks/CU
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(convert_rgba8_kernel, dim3(blocks), dim3(256), 0, s, (const float4*)d_rgba_f32, (uint32_t*)d_rgba8, W,
+                       H, scale, rotate180);
+    MC_HIP_TRY(hipGetLastError());
+    return MC_OK;
+}
+
+}  // namespace mc

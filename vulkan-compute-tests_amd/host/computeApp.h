@@ -1,0 +1,61 @@
+// ComputeApp — the HIP/MI355X stand-in for the reference's `VulkanComputeApp`
+// (src/vulkanComputeApp.h:30-127): same public lifecycle as driven by src/main.cpp:28-33
+//     init() -> preRun() -> run() -> saveRenderedImage(filename)
+// but underneath it owns an mc_context (include/mc_compute.h) instead of a VkInstance/VkDevice/
+// VkPipeline/VkCommandBuffer.  The Vulkan plumbing (descriptor sets, pipeline layout, SPIR-V loading,
+// memory-type search, fences) has no counterpart: a HIP launch needs none of it.
+//
+// Error convention: the reference prints+asserts on VkResult (vulkanComputeApp.h:16-24), exit(-1)s
+// (:11-12) or throws std::runtime_error (vulkanComputeApp.cpp:78,218,...).  Here every non-zero
+// C-ABI status becomes a std::runtime_error, so main's catch block (main.cpp:35-38) keeps its
+// behaviour: message on stdout, EXIT_FAILURE.
+#ifndef COMPUTEAPP_H_
+#define COMPUTEAPP_H_
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mc_compute.h"
+
+struct ComputeApp {
+    virtual ~ComputeApp();
+
+    void init();                 // vulkanComputeApp.cpp:443-449 (createInstance/findPhysicalDevice/createDevice)
+    virtual void preRun() {}     // apps allocate the output storage buffer here (mandelbrotApp.h:22-25)
+    virtual void run();          // vulkanComputeApp.cpp:451-466: record the dispatch(es), submit, wait
+
+    // Records what run() will execute (the reference records vkCmdDispatch calls here).
+    virtual void createCommandBuffer() {}
+    // Submits and blocks until the device is done (vulkanComputeApp.cpp:645-671).
+    virtual void runCommandBuffer() = 0;
+
+    virtual void saveRenderedImage(const char* png_filename) = 0;   // vulkanComputeApp.h:67
+
+    // -- additions (reference defaults when untouched) --
+    void setNumGpus(int n) { numGpus = n < 1 ? 1 : n; }   // row-tiled multi-GPU render + RCCL gather
+    void setDevice(int d) { deviceIndex = d; }
+    void setQuiet(bool q) { quiet = q; }
+    double lastRunMilliseconds() const { return lastRunMs; }
+
+protected:
+    void createBuffer(uint64_t bufferSizeBytes);   // vulkanComputeApp.cpp:489-533: the output storage buffer
+    static void check(int status, const char* what);
+
+    mc_context* ctx = nullptr;
+    mc_multi* multi = nullptr;
+    int numGpus = 1;
+    int deviceIndex = 0;   // the reference always takes devices[0] (vulkanComputeApp.cpp:163)
+    bool quiet = false;
+    double lastRunMs = 0.0;
+    // The storage buffer, host side: vec4 fp32 per pixel, row-major (what vkMapMemory exposes to
+    // getRenderedImage in the reference).
+    std::vector<float> buffer;
+};
+
+// Drop-in alias: code written against the reference's base-class name keeps compiling.
+using VulkanComputeApp = ComputeApp;
+
+#endif  // COMPUTEAPP_H_

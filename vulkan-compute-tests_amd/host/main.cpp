@@ -1,0 +1,82 @@
+// Entry point — same shape as the reference's src/main.cpp:15-41: mode selected by macro, the path
+// tracer takes argv[1] = spp (default 500) and argv[2] = resy (default 600) with resx = resy*3/2, the
+// Mandelbrot app renders 2000x2000; lifecycle init() -> preRun() -> run() -> saveRenderedImage();
+// std::runtime_error -> message + EXIT_FAILURE.  Options (never reinterpreting the two positional
+// arguments) expose what the reference hard-codes: --gpus N, --out FILE, --quiet, and per mode
+// --width/--height/--max-iter/--centre X Y/--scale SX SY/--precision f32|ds  or  --math strict|fast.
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+// make sure that one token is defined
+#if !defined(MANDELBROT_MODE) && !defined(PATHTRACER_MODE)
+#define PATHTRACER_MODE
+#endif
+
+#if defined(MANDELBROT_MODE)
+#include "mandelbrotApp.h"
+#elif defined(PATHTRACER_MODE)
+#include "pathtracerApp.h"
+#endif
+
+int main(int argc, char* argv[]) {
+    printf("starting main!\n");
+
+    // split options from positional arguments
+    std::vector<const char*> pos;
+    int gpus = 1;
+    bool quiet = false;
+    const char* outFile = nullptr;
+    uint32_t width = 2000, height = 2000, maxIter = 128, precision = MC_PRECISION_F32, mathMode = MC_PT_MATH_STRICT;
+    double cx = -0.445, cy = 0.0, sx = 2.34, sy = 2.34;
+    bool viewSet = false;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto need = [&](int n) { if (i + n >= argc) { printf("missing value for %s\n", a.c_str()); exit(EXIT_FAILURE); } };
+        if (a == "--gpus") { need(1); gpus = atoi(argv[++i]); }
+        else if (a == "--out") { need(1); outFile = argv[++i]; }
+        else if (a == "--quiet") quiet = true;
+        else if (a == "--width") { need(1); width = (uint32_t)atoi(argv[++i]); }
+        else if (a == "--height") { need(1); height = (uint32_t)atoi(argv[++i]); }
+        else if (a == "--max-iter") { need(1); maxIter = (uint32_t)atoi(argv[++i]); }
+        else if (a == "--centre") { need(2); cx = atof(argv[++i]); cy = atof(argv[++i]); viewSet = true; }
+        else if (a == "--scale") { need(2); sx = atof(argv[++i]); sy = atof(argv[++i]); viewSet = true; }
+        else if (a == "--precision") { need(1); precision = std::strcmp(argv[++i], "ds") == 0 ? MC_PRECISION_DS : MC_PRECISION_F32; }
+        else if (a == "--math") { need(1); mathMode = std::strcmp(argv[++i], "fast") == 0 ? MC_PT_MATH_FAST : MC_PT_MATH_STRICT; }
+        else pos.push_back(argv[i]);
+    }
+    (void)width; (void)height; (void)maxIter; (void)precision; (void)mathMode; (void)cx; (void)cy; (void)sx; (void)sy; (void)viewSet;
+
+#if defined(MANDELBROT_MODE)
+    MandelbrotApp app = MandelbrotApp(width, height);   // reference: 2000 x 2000 (main.cpp:20)
+    app.setMaxIter(maxIter);
+    if (viewSet) app.setView(cx, cy, sx, sy);
+    app.setPrecision(precision);
+#elif defined(PATHTRACER_MODE)
+    const int32_t spp = pos.size() > 0 ? atoi(pos[0]) : 500;                           // samples per pixel
+    const uint32_t resy = pos.size() > 1 ? static_cast<uint32_t>(atoi(pos[1])) : 600;  // vertical pixel resolution
+    const uint32_t resx = resy * 3 / 2;                                                // horizontal pixel resolution
+    PathtracerApp app = PathtracerApp(resx, resy, spp);
+    app.setMathMode(mathMode);
+#endif
+    app.setNumGpus(gpus);
+    app.setQuiet(quiet);
+
+    try {
+        // the reference calls init()/preRun() outside its try block (main.cpp:28-29); a missing device
+        // then terminates via an uncaught exception.  Kept inside here so the failure is reported.
+        app.init();
+        app.preRun();
+        printf("now running app!\n");
+        app.run();
+        if (outFile) app.saveRenderedImage(outFile);
+        else app.saveRenderedImage();
+    } catch (const std::runtime_error& e) {
+        printf("%s\n", e.what());
+        return EXIT_FAILURE;
+    }
+
+    return EXIT_SUCCESS;
+}

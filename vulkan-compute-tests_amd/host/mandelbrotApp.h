@@ -1,0 +1,79 @@
+// MandelbrotApp — mirrors src/mandelbrotApp.h:8-194 of the reference on top of ComputeApp.
+#ifndef MANDELBROTAPP_H_
+#define MANDELBROTAPP_H_
+
+#include "computeApp.h"
+#include "pngWriter.h"
+
+struct MandelbrotApp : public ComputeApp {
+    // Same signature as the reference (mandelbrotApp.h:10).  workgroupSize is accepted for source
+    // compatibility; the HIP kernels choose their own tiling (8x8 pixels per wave64).
+    MandelbrotApp(const uint32_t resx, const uint32_t resy, const uint32_t workgroupSize = 32) {
+        this->resx = resx;
+        this->resy = resy;
+        this->workgroupSize = workgroupSize;
+        bufferSize = (uint64_t)sizeof(Pixel) * resx * resy;   // mandelbrotApp.h:16 (uint32_t there)
+        mc_mandelbrot_default_params(resx, resy, &params);    // M=128, centre (-0.445,0), scale 2.34, kColor {0.1,0.7,0.6,0}
+    }
+    virtual ~MandelbrotApp() {}
+
+    // -- additions: the reference hard-codes these in the shader (mandelbrot.comp:5-6,38,40) --
+    void setMaxIter(uint32_t m) { params.max_iter = m; }
+    void setView(double cx, double cy, double sx, double sy) {
+        split(cx, params.centre_x_hi, params.centre_x_lo);
+        split(cy, params.centre_y_hi, params.centre_y_lo);
+        split(sx, params.scale_x_hi, params.scale_x_lo);
+        split(sy, params.scale_y_hi, params.scale_y_lo);
+    }
+    void setPrecision(uint32_t precision) { params.precision = precision; }   // MC_PRECISION_F32 / MC_PRECISION_DS
+
+    virtual void preRun() override {
+        if (!quiet) { printf(" * before createBuffer()\n"); fflush(stdout); }
+        createBuffer(bufferSize);   // output buffer
+    }
+
+    virtual void createCommandBuffer() override {
+        // push constant kColor (mandelbrotApp.h:139-141) and ONE dispatch over the whole image (:146)
+        params.k_color[0] = 0.1f; params.k_color[1] = 0.7f; params.k_color[2] = 0.6f; params.k_color[3] = 0.0f;
+        params.row_begin = 0; params.row_end = resy;
+    }
+
+    virtual void runCommandBuffer() override {
+        if (multi) check(mc_multi_mandelbrot_render(multi, &params, buffer.data(), nullptr), "mc_multi_mandelbrot_render");
+        else check(mc_mandelbrot_render(ctx, &params, buffer.data(), nullptr), "mc_mandelbrot_render");
+    }
+
+    // mandelbrotApp.h:149-170: u8 = static_cast<uint8_t>(scale * c), alpha 255.  The cast is UB out of
+    // range; the reference binary on x86-64 truncates to int32 and keeps the low byte — stated explicitly.
+    void getRenderedImage(std::vector<uint8_t>& image, const uint32_t resx, const uint32_t resy, float floatScaleFactor) {
+        const Pixel* p = reinterpret_cast<const Pixel*>(buffer.data());
+        image.resize((size_t)resx * resy * 4);
+        for (size_t i = 0; i < (size_t)resx * resy; i++) {
+            image[4 * i + 0] = x86FloatToU8(floatScaleFactor * p[i].r);
+            image[4 * i + 1] = x86FloatToU8(floatScaleFactor * p[i].g);
+            image[4 * i + 2] = x86FloatToU8(floatScaleFactor * p[i].b);
+            image[4 * i + 3] = 255u;
+        }
+    }
+
+    virtual void saveRenderedImage(const char* png_filename = "mandelbrot.png") override {
+        std::vector<uint8_t> image;
+        constexpr float scaleFactor = 255.0f;   // mandelbrotApp.h:174
+        getRenderedImage(image, resx, resy, scaleFactor);
+        printf("writing %s\n", png_filename);
+        std::string err = pngwriter::encodeFile(png_filename, image.data(), resx, resy);
+        if (!err.empty()) printf("encoder error: %s", err.c_str());   // printed, not thrown (mandelbrotApp.h:183)
+    }
+
+    const std::vector<float>& storageBuffer() const { return buffer; }
+
+private:
+    struct Pixel { float r, g, b, a; };   // mandelbrotApp.h:187-189
+    static void split(double d, float& hi, float& lo) { hi = (float)d; lo = (float)(d - (double)hi); }
+    uint64_t bufferSize;
+    uint32_t resx, resy;
+    uint32_t workgroupSize;
+    mc_mandelbrot_params params;
+};
+
+#endif  // MANDELBROTAPP_H_

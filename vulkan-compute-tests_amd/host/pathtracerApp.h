@@ -1,0 +1,111 @@
+// PathtracerApp — mirrors src/pathtracerApp.h:42-397 of the reference on top of ComputeApp.
+#ifndef PATHTRACERAPP_H_
+#define PATHTRACERAPP_H_
+
+#include <cstring>
+
+#include "computeApp.h"
+#include "pngWriter.h"
+
+struct PathtracerApp : public ComputeApp {
+    struct pushConst_t {          // pathtracerApp.h:44-47
+        uint32_t imgdim[2];       // { WIDTH, HEIGHT }
+        uint32_t samps[2];        // { 0, spp }
+    } pushConst;
+
+    // Same signature as the reference (pathtracerApp.h:49).
+    PathtracerApp(const uint32_t resx, const uint32_t resy, const int32_t spp, const uint32_t workgroupSize = 16) {
+        this->resx = resx;
+        this->resy = resy;
+        this->spp = spp;
+        this->workgroupSize = workgroupSize;
+        bufferSize = (uint64_t)sizeof(Pixel) * resx * resy;
+        if (!quiet) printf("in PathtracerApp ctor\n");
+        pushConst.imgdim[0] = resx;
+        pushConst.imgdim[1] = resy;
+        pushConst.samps[0] = 0;
+        pushConst.samps[1] = (uint32_t)spp;
+        mc_pathtrace_default_params(resx, resy, (uint32_t)spp, &params);
+        const float *pl, *sp; uint32_t np, ns;
+        mc_pathtrace_default_scene(&pl, &np, &sp, &ns);   // the tables of pathtracerApp.h:14-39
+        planes.assign(pl, pl + 12 * np);
+        spheres.assign(sp, sp + 12 * ns);
+    }
+    virtual ~PathtracerApp() {}
+
+    // -- additions --
+    void setMathMode(uint32_t mode) { params.math_mode = mode; }   // MC_PT_MATH_STRICT / MC_PT_MATH_FAST
+    void setScene(const float* pl, uint32_t np, const float* sp, uint32_t ns) {
+        planes.assign(pl, pl + 12 * np);
+        spheres.assign(sp, sp + 12 * ns);
+    }
+
+    virtual void preRun() override {
+        if (!quiet) { printf(" * before createBuffer()\n"); fflush(stdout); }
+        createBuffer(bufferSize);   // output buffer; the two scene SSBOs of the reference (pathtracerApp.h:129-198)
+                                    // become kernel arguments, there is nothing to upload here
+    }
+
+    // The reference records spp dispatches, one push-constant update each, with no barrier in between
+    // (pathtracerApp.h:361-376).  Here the whole samps.x range [0,spp) is ONE launch with the sample
+    // loop fused in registers, accumulating in the barrier-serialised order s = 0..spp-1.
+    virtual void createCommandBuffer() override {
+        if (!quiet) { printf("\n   ### recording fused spp loop: samples [0,%d) ###\n\n", spp); fflush(stdout); }
+        params.width = pushConst.imgdim[0]; params.height = pushConst.imgdim[1];
+        params.spp = pushConst.samps[1];
+        params.sample_begin = 0; params.sample_end = pushConst.samps[1];
+        params.row_begin = 0; params.row_end = resy;
+    }
+
+    virtual void runCommandBuffer() override {
+        if (multi)
+            check(mc_multi_pathtrace_render(multi, &params, planes.data(), (uint32_t)planes.size() / 12, spheres.data(),
+                                            (uint32_t)spheres.size() / 12, buffer.data()), "mc_multi_pathtrace_render");
+        else
+            check(mc_pathtrace_render(ctx, &params, planes.data(), (uint32_t)planes.size() / 12, spheres.data(),
+                                      (uint32_t)spheres.size() / 12, buffer.data()), "mc_pathtrace_render");
+    }
+
+    // pathtracerApp.h:202-223
+    void getRenderedImage(std::vector<uint8_t>& image, const uint32_t resx, const uint32_t resy, float floatScaleFactor) {
+        const Pixel* p = reinterpret_cast<const Pixel*>(buffer.data());
+        image.resize((size_t)resx * resy * 4);
+        for (size_t i = 0; i < (size_t)resx * resy; i++) {
+            image[4 * i + 0] = x86FloatToU8(floatScaleFactor * p[i].r);
+            image[4 * i + 1] = x86FloatToU8(floatScaleFactor * p[i].g);
+            image[4 * i + 2] = x86FloatToU8(floatScaleFactor * p[i].b);
+            image[4 * i + 3] = 255u;
+        }
+    }
+
+    virtual void saveRenderedImage(const char* png_filename = "pathtracer.png") override {
+        std::vector<uint8_t> image;
+        constexpr float scaleFactor = 1.0f;   // pathtracerApp.h:227
+        getRenderedImage(image, resx, resy, scaleFactor);
+        printf("writing %s\n", png_filename);
+        // due to the pinhole camera the image is upside-down and mirrored — undo that (pathtracerApp.h:235-243)
+        uint32_t* pRGBA = reinterpret_cast<uint32_t*>(image.data());
+        for (uint32_t y = 0; y < resy; y++) {
+            for (uint32_t x = 0; x < resx / 2; x++) {
+                uint32_t from = x + y * resx;
+                uint32_t to = (resx - 1) - x + ((resy - 1) - y) * resx;
+                std::swap(pRGBA[from], pRGBA[to]);
+            }
+        }
+        std::string err = pngwriter::encodeFile(png_filename, image.data(), resx, resy);
+        if (!err.empty()) printf("encoder error: %s", err.c_str());
+    }
+
+    const std::vector<float>& storageBuffer() const { return buffer; }
+
+private:
+    struct Pixel { float r, g, b, a; };
+    uint64_t bufferSize;
+    uint32_t resx, resy;
+    int32_t spp;
+    uint32_t workgroupSize;
+    mc_pathtrace_params params;
+    std::vector<float> planes, spheres;
+};
+
+#endif  // PATHTRACERAPP_H_
