@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--spp", type=int, default=None, help="override spp (diagnostics only; invalidates the headline)")
+    ap.add_argument("--width", type=int, default=None, help="override image width (diagnostics only)")
+    ap.add_argument("--height", type=int, default=None, help="override per-GPU image height (diagnostics only)")
     return ap.parse_args()
 
 
@@ -87,12 +89,17 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=n, device_id=torch.device("cuda", local_rank))
     ctx = B.Context(local_rank)
     dev_name, cus, _ = ctx.device_info()
-    stream = torch.cuda.current_stream().cuda_stream
+    # a non-default torch stream: its handle is non-zero, so the C ABI launches on exactly this stream and the
+    # torch.cuda.Event pairs below bracket the kernel (a NULL handle would select the context's own stream)
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
 
     # ---- workload ---------------------------------------------------------------------------------
     wl = args.workload
     if wl == "pathtrace":
-        W, Hbase, spp = K2["W"], K2["H"], args.spp or K2["spp"]
+        W, Hbase, spp = args.width or K2["W"], args.height or K2["H"], args.spp or K2["spp"]
         H = Hbase * n
         math_mode = B.PT_MATH_FAST if args.math == "fast" else B.PT_MATH_STRICT
         p = B.pathtrace_params(W, H, spp, math_mode=math_mode, row_begin=rank * ROW_BLOCK, row_end=H,
@@ -104,7 +111,7 @@ def main():
         metric, unit = "path-traced samples/s", "samples/s"
         workload_name = f"pathtrace {W}x{H} spp{spp} default-scene math={args.math}"
     else:
-        W, Hbase, M = K1["W"], K1["H"], K1["M"]
+        W, Hbase, M = args.width or K1["W"], args.height or K1["H"], K1["M"]
         H = Hbase * n
         ds = wl == "mandelbrot_ds"
         kw = dict(max_iter=M, row_begin=rank * ROW_BLOCK, row_end=H, row_block=ROW_BLOCK if n > 1 else 0,
@@ -230,7 +237,10 @@ def main():
         O = entry.load_oracle()   # TEST INFRASTRUCTURE, used here only as the timed CPU baseline
         threads = O.hardware_threads()
         if wl == "pathtrace":
-            s_spp = 4
+            t = time.perf_counter()   # probe, then size the sample for ~10-20 s of CPU work
+            O.pathtrace(W, H, p.spp, math_mode=O.MATH_LIBM, sample_begin=0, sample_end=1, nthreads=threads)
+            probe = time.perf_counter() - t
+            s_spp = int(max(1, min(p.spp, 12.0 / max(probe, 1e-3))))
             t = time.perf_counter()
             O.pathtrace(W, H, p.spp, math_mode=O.MATH_LIBM, sample_begin=0, sample_end=s_spp, nthreads=threads)
             cdt = time.perf_counter() - t
@@ -238,17 +248,21 @@ def main():
                                    "sample": f"samples 0..{s_spp - 1} of {p.spp} over the full {W}x{H} image "
                                              f"({W * H * s_spp} samples, {cdt:.1f} s)"}
         else:
-            rows = list(range(0, H, 16))   # every 16th row: same interior/exterior mix as the full image
-            t = time.perf_counter()
-            tot = 0
+            rows = list(range(0, H, 4))   # every 4th row: same interior/exterior mix as the full image
+            from concurrent.futures import ThreadPoolExecutor
             view = O.make_view(*(K4_VIEW["centre"] + K4_VIEW["scale"])) if wl == "mandelbrot_ds" else O.REF_VIEW
-            for r in rows:
+
+            def one_row(r):   # ctypes releases the GIL: one oracle row per worker thread
                 itc = O.mandelbrot_iters(W, H, p.max_iter, view=view, precision=int(wl == "mandelbrot_ds"), row_begin=r,
                                          row_end=r + 1, nthreads=1)
-                tot += O.mandel_pixel_iters(itc, p.max_iter)
+                return O.mandel_pixel_iters(itc, p.max_iter)
+
+            t = time.perf_counter()
+            with ThreadPoolExecutor(min(threads, 64)) as ex:
+                tot = sum(ex.map(one_row, rows))
             cdt = time.perf_counter() - t
-            out["cpu_baseline"] = {"value": tot / cdt, "unit": unit, "cores": 1, "kind": "port",
-                                   "sample": f"every 16th row of the {W}x{H} image ({tot} pixel-iters, {cdt:.1f} s)"}
+            out["cpu_baseline"] = {"value": tot / cdt, "unit": unit, "cores": min(threads, 64), "kind": "port",
+                                   "sample": f"every 4th row of the {W}x{H} image ({tot} pixel-iters, {cdt:.1f} s)"}
 
     if rank == 0:
         print(json.dumps(out), flush=True)
