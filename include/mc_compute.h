@@ -102,6 +102,12 @@ enum {
     MC_PT_MATH_FAST = 1    /* gfx950 hardware rcp/rsq/sqrt/sin/cos/exp/log: toleranced parity    */
 };
 
+/* mc_pathtrace_params.flags — diagnostics; every combination produces bit-identical buffers */
+enum {
+    MC_PT_GENERIC_KERNEL = 1u << 0 /* never use the axis-aligned-slab specialisation of the plane test */
+};
+#define MC_PT_FORCE_S(s) ((uint32_t)(s) << 8) /* force the sample-parallel width: 1, 4 or 16 (0 = automatic) */
+
 typedef struct mc_pathtrace_params {
     uint32_t width, height;            /* push constant imgdim (pathtracerApp.h:44-47,58-59)            */
     uint32_t spp;                      /* push constant samps.y (pathtracerApp.h:61; main.cpp:22)        */

@@ -171,6 +171,42 @@ def test_pathtrace_strict_bit_exact(ctx, B, O, W, H, spp):
     assert np.array_equal(bits(out), bits(ref))
 
 
+@pytest.mark.parametrize("math", ["strict", "fast"])
+def test_pathtrace_kernel_variants_bit_identical(ctx, B, O, math):
+    """Sample-parallel width S in {1,4,16} and the slab specialisation are pure re-mappings of the same
+    arithmetic: every variant must produce the same bits (strict additionally == oracle).  spp = 21 leaves a
+    ragged last round for S = 4 and S = 16; 37x23 leaves ragged wave tiles."""
+    W, H, spp = 37, 23, 21
+    mode = B.PT_MATH_STRICT if math == "strict" else B.PT_MATH_FAST
+    outs = {}
+    for S in (1, 4, 16):
+        for generic in (0, B.PT_GENERIC_KERNEL):
+            p = B.pathtrace_params(W, H, spp, math_mode=mode, flags=B.pt_force_s(S) | generic)
+            outs[(S, generic)] = ctx.pathtrace(p)
+    first = outs[(1, 0)]
+    for k, v in outs.items():
+        assert np.array_equal(bits(v), bits(first)), k
+    if math == "strict":
+        assert np.array_equal(bits(first), bits(O.pathtrace(W, H, spp, math_mode=O.MATH_MC)))
+    # automatic choice of S on a tile + progressive range (sample_begin > 0, ragged rounds on both ends)
+    p1 = B.pathtrace_params(W, H, spp, math_mode=mode, sample_begin=0, sample_end=5, flags=B.pt_force_s(4))
+    p2 = B.pathtrace_params(W, H, spp, math_mode=mode, sample_begin=5, sample_end=21, flags=B.pt_force_s(16))
+    assert np.array_equal(bits(ctx.pathtrace(p2, acc=ctx.pathtrace(p1))), bits(first))
+
+
+def test_pathtrace_slab_analysis_rejects_non_box_scenes(ctx, B, O):
+    """Scenes that are not an index-ordered axis-aligned box must fall back to the generic kernel and still
+    match the oracle: permuted plane order (y planes before x planes) and a tilted plane."""
+    pl = O.DEFAULT_PLANES.reshape(6, 12)
+    permuted = pl[[2, 3, 0, 1, 4, 5]].copy()
+    tilted = pl.copy()
+    tilted[2, :3] = np.array([0.0, 0.8, 0.6], np.float32)   # unit normal, not axis aligned
+    for planes in (permuted, tilted):
+        out = ctx.pathtrace(B.pathtrace_params(32, 24, 4), planes=planes, spheres=O.DEFAULT_SPHERES)
+        ref = O.pathtrace(32, 24, 4, planes=planes, spheres=O.DEFAULT_SPHERES, math_mode=O.MATH_MC)
+        assert np.array_equal(bits(out), bits(ref))
+
+
 def test_pathtrace_default_scene_table_matches(B, O):
     planes, spheres = B.default_scene()
     assert np.array_equal(bits(planes), bits(O.DEFAULT_PLANES))

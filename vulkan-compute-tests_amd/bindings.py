@@ -18,6 +18,11 @@ MC_OK = 0
 PRECISION_F32, PRECISION_DS = 0, 1
 PT_MATH_STRICT, PT_MATH_FAST = 0, 1
 MANDEL_FMA = 1
+PT_GENERIC_KERNEL = 1
+
+
+def pt_force_s(s):
+    return int(s) << 8
 
 
 class McError(RuntimeError):
@@ -141,13 +146,14 @@ def mandelbrot_params(width, height, max_iter=128, precision=PRECISION_F32, cent
 
 
 def pathtrace_params(width, height, spp, math_mode=PT_MATH_STRICT, sample_begin=0, sample_end=None, max_depth=12,
-                     row_begin=0, row_end=None, row_block=0, row_stride=0):
+                     row_begin=0, row_end=None, row_block=0, row_stride=0, flags=0):
     p = PathtraceParams()
     _check(lib().mc_pathtrace_default_params(width, height, spp, C.byref(p)), "mc_pathtrace_default_params")
     p.math_mode, p.sample_begin, p.max_depth = math_mode, sample_begin, max_depth
     p.sample_end = spp if sample_end is None else sample_end
     p.row_begin, p.row_end = row_begin, height if row_end is None else row_end
     p.row_block, p.row_stride = row_block, row_stride
+    p.flags = flags
     return p
 
 

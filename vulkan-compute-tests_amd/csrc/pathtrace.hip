@@ -1,267 +1,16 @@
-// Path tracer kernel for gfx950 (MI355X).
-//
-// Replaces shaders/pathTracer.comp:343-458 AND the host-side sample loop that records `spp`
-// dispatches (src/pathtracerApp.h:358-378): the whole [sample_begin, sample_end) range of one pixel
-// runs inside one work-item, the accumulator lives in registers, and the 16-B storage-buffer entry is
-// written once (the reference re-reads and re-writes it every sample through host-visible memory).
-//
-// Parity rules:
-//  * samples are accumulated in sample order, `acc += accrad / spp` per sample (pathTracer.comp:451-452);
-//  * rand01 is the reference's stateless integer hash, bit-exact (pathTracer.comp:107-110);
-//  * every fp32 expression keeps the GLSL source order, unfused (this TU is built -ffp-contract=off);
-//  * strict mode uses IEEE divide/sqrt and the explicit mc_math.h algorithms for sin/cos/pow, which
-//    makes the output buffer bit-identical to the CPU oracle; fast mode uses the gfx950 hardware
-//    approximations and is compared under a stated tolerance.
-//
-// Scene constants (432 B for the default scene) arrive in the kernel-argument segment: uniform
-// accesses in the intersection loops become scalar loads / SGPR operands (no VGPRs, no LDS traffic);
-// the per-lane material fetch by hit index reads a copy staged in LDS at kernel start.
+// Host side of the path tracer launch: argument validation, camera basis, scene analysis (slab
+// specialisation, emissive mask), choice of the sample-parallel width S.  Device code: pathtrace_kernel.h.
 #include <cmath>
 #include <cstring>
 
-#include "mc_internal.h"
-#include "mc_math.h"
+#include "pathtrace_kernel.h"
 
 namespace mc {
 
+using pt::PTArgs;
+using pt::v3;
+
 namespace {
-
-constexpr int kMaxPlanes = 16;
-constexpr int kMaxSpheres = 16;
-
-struct v3 {
-    float x, y, z;
-};
-
-// Scene in the order the kernels consume it.  obj[] keeps the reference's 12-float records
-// (planes first, then spheres) for the per-lane material fetch; r2[] caches radius*radius (the fp32
-// product the shader computes at pathTracer.comp:318, evaluated once on the host in fp32).
-struct SceneArgs {
-    uint32_t n_planes, n_spheres;
-    uint32_t emissive_mask;   // bit i set <=> dot(spheres[i].e, spheres[i].e) > 0  (pathTracer.comp:407)
-    uint32_t pad;
-    float obj[(kMaxPlanes + kMaxSpheres) * 12];
-    float r2[kMaxSpheres];
-};
-
-struct PTArgs {
-    uint32_t W, H, spp, sample_begin, sample_end, max_depth, row_begin, row_end, row_block, row_stride;
-    // camera basis (pathTracer.comp:352-353,360), evaluated once on the host with the same IEEE ops
-    v3 cam_o, cam_d, cx, cy, lc;
-    float4* __restrict__ out;   // tile-local storage rows
-    SceneArgs scene;
-};
-
-__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return v3{a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return v3{a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ v3 operator*(v3 a, v3 b) { return v3{a.x * b.x, a.y * b.y, a.z * b.z}; }
-__device__ __forceinline__ v3 operator*(v3 a, float s) { return v3{a.x * s, a.y * s, a.z * s}; }
-__device__ __forceinline__ v3 operator-(v3 a) { return v3{-a.x, -a.y, -a.z}; }
-__device__ __forceinline__ float dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-// GLSL cross: (a.y*b.z - b.y*a.z, a.z*b.x - b.z*a.x, a.x*b.y - b.x*a.y)
-__device__ __forceinline__ v3 cross(v3 a, v3 b) {
-    return v3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
-}
-template <bool Fast> __device__ __forceinline__ v3 normalize(v3 a) { return a * dm::inversesqrt<Fast>(dot(a, a)); }
-template <bool Fast> __device__ __forceinline__ v3 divs(v3 a, float s) {
-    return v3{dm::fdiv<Fast>(a.x, s), dm::fdiv<Fast>(a.y, s), dm::fdiv<Fast>(a.z, s)};
-}
-// reflect(I,N) = I - 2*dot(N,I)*N
-__device__ __forceinline__ v3 reflect(v3 I, v3 N) { return I - N * (2.0f * dot(N, I)); }
-__device__ __forceinline__ v3 select(bool c, v3 a, v3 b) { return v3{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
-
-// rand01 — pathTracer.comp:107-110 (float(0xffffffffU) rounds to 2^32: the scale is exactly 2^-32)
-__device__ __forceinline__ v3 rand01(uint32_t x, uint32_t y, uint32_t z) {
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        uint32_t nx = ((x >> 8) ^ y) * 1103515245u;
-        uint32_t ny = ((y >> 8) ^ z) * 1103515245u;
-        uint32_t nz = ((z >> 8) ^ x) * 1103515245u;
-        x = nx; y = ny; z = nz;
-    }
-    const float s = 2.3283064365386963e-10f;   // 2^-32
-    return v3{(float)x * s, (float)y * s, (float)z * s};
-}
-
-constexpr float kEps = 1e-4f, kTriEps = 1e-7f, kInf = 1e20f;   // pathTracer.comp:103-105
-constexpr float kPi = 3.141592653589793f;                       // :102
-
-// intersect — pathTracer.comp:112-131 + :316-341.  Returns the hit object id (planes 0..NP-1, spheres
-// NP..NP+NS-1) or -1, and the ray parameter.  NP/NS < 0 select run-time counts.
-template <bool Fast, int NP, int NS>
-__device__ __forceinline__ int intersect(const SceneArgs& sc, v3 o, v3 d, float& t_out) {
-    const int np = NP >= 0 ? NP : (int)sc.n_planes;
-    const int ns = NS >= 0 ? NS : (int)sc.n_spheres;
-    float t = kInf;
-    int id = -1;
-#pragma unroll
-    for (int i = 0; i < np; i++) {
-        const float* pl = sc.obj + 12 * i;
-        v3 n{pl[0], pl[1], pl[2]};
-        float denom = dot(d, n);                                         // :118
-        if (denom > kTriEps) {                                           // :119
-            float dd = dm::fdiv<Fast>(pl[3] - dot(o, n), denom);         // :120
-            if (dd < t) { t = dd; id = i; }                              // :121
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < ns; i++) {
-        const float* sp = sc.obj + 12 * (np + i);
-        v3 oc = v3{sp[0], sp[1], sp[2]} - o;                             // :317
-        float b = dot(oc, d);                                            // :318
-        float det = (b * b - dot(oc, oc)) + sc.r2[i];
-        if (!(det < 0.0f)) {                                             // :319
-            float sq = dm::fsqrt<Fast>(det);
-            float dd = b - sq;                                           // :322,324
-            if (dd <= kEps) {                                            // :325
-                dd = b + sq;                                             // :323,326
-                if (dd <= kEps) dd = kInf;                               // :327
-            }
-            if (dd < t) { t = dd; id = np + i; }                         // :333
-        }
-    }
-    t_out = t;
-    return (t < kInf) ? id : -1;                                         // :336
-}
-
-// One sample: returns accrad (pathTracer.comp:356-449).
-template <bool Fast, int NP, int NS>
-__device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restrict__ lds_obj, uint32_t gx, uint32_t gy,
-                                           uint32_t samp) {
-    const SceneArgs& sc = a.scene;
-    const int np = NP >= 0 ? NP : (int)sc.n_planes;
-    const int ns = NS >= 0 ? NS : (int)sc.n_spheres;
-    // -- sample sensor (:357-362)
-    v3 r0 = rand01(gx, gy, samp);
-    float rnd2x = 2.0f * r0.x, rnd2y = 2.0f * r0.y;
-    float tentx = rnd2x < 1.0f ? dm::fsqrt<Fast>(rnd2x) - 1.0f : 1.0f - dm::fsqrt<Fast>(2.0f - rnd2x);
-    float tenty = rnd2y < 1.0f ? dm::fsqrt<Fast>(rnd2y) - 1.0f : 1.0f - dm::fsqrt<Fast>(2.0f - rnd2y);
-    float stratx = (float)((samp / 2u) % 2u), straty = (float)(samp % 2u);
-    float sx = (dm::fdiv<Fast>((float)gx + 0.5f * ((0.5f + stratx) + tentx), (float)a.W) - 0.5f) * 0.036f;
-    float sy = (dm::fdiv<Fast>((float)gy + 0.5f * ((0.5f + straty) + tenty), (float)a.H) - 0.5f) * 0.024f;
-    v3 spos = (a.cam_o + a.cx * sx) + a.cy * sy;                          // :360
-    v3 accrad{0.0f, 0.0f, 0.0f}, accmat{1.0f, 1.0f, 1.0f};               // :361
-    v3 ro = a.lc, rd = normalize<Fast>(a.lc - spos);                      // :362
-    float emissive = 1.0f;                                                // :365
-
-    for (uint32_t depth = 0; depth < a.max_depth; depth++) {              // :367
-        float t;
-        int id = intersect<Fast, NP, NS>(sc, ro, rd, t);
-        if (id < 0) break;   // :369 `continue` with an unchanged ray misses again at every later depth: no effect
-        v3 x = ro + rd * t;                                               // :374 (o + t*d: fp32 mul is commutative)
-        const float* obj = lds_obj + 12 * id;                             // per-lane fetch from LDS
-        const bool is_sphere = id >= np;
-        v3 geo{obj[0], obj[1], obj[2]};
-        v3 emi{obj[4], obj[5], obj[6]};
-        v3 col{obj[8], obj[9], obj[10]};
-        int mat = (int)__builtin_floorf(obj[11] + 0.5f);                  // :378/:384
-        v3 n = is_sphere ? normalize<Fast>(x - geo) : geo;                // :381/:387
-        v3 nl = dot(n, rd) < 0.0f ? n : -n;                               // :390
-        accrad = accrad + (accmat * emi) * emissive;                      // :391
-        accmat = accmat * col;                                            // :392
-        v3 rnd = rand01(gx, gy, samp * a.max_depth + depth);              // :393
-        float p = dm::gmax(dm::gmax(col.x, col.y), col.z);               // :394
-        if (depth > 5) {                                                  // :395
-            if (rnd.z >= p) break;                                        // :396
-            accmat = divs<Fast>(accmat, p);                               // :397
-        }
-        if (mat == 1) {                                                   // :400 diffuse
-            for (int i = 0; i < ns; i++) {                                // :403
-                if (!((sc.emissive_mask >> i) & 1u)) continue;            // :407 (uniform)
-                const float* ls = sc.obj + 12 * (np + i);
-                v3 le{ls[4], ls[5], ls[6]};
-                v3 xc = v3{ls[0], ls[1], ls[2]} - x;                      // :408
-                v3 sw = normalize<Fast>(xc);                              // :409
-                v3 su = normalize<Fast>(cross((__builtin_fabsf(sw.x) > 0.1f ? v3{0, 1, 0} : v3{1, 0, 0}), sw));
-                v3 sv = cross(sw, su);
-                float cos_a_max = dm::fsqrt<Fast>(1.0f - dm::fdiv<Fast>(sc.r2[i], dot(xc, xc)));   // :410
-                float cos_a = (1.0f - rnd.x) + rnd.x * cos_a_max;         // :411
-                float sin_a = dm::fsqrt<Fast>(1.0f - cos_a * cos_a);
-                float phi = (2.0f * kPi) * rnd.y;                         // :412
-                float sphi, cphi;
-                dm::sincos_angle<Fast>(phi, rnd.y, sphi, cphi);
-                v3 l = normalize<Fast>(((su * cphi) * sin_a + (sv * sphi) * sin_a) + sw * cos_a);   // :413
-                float tne;
-                int idne = intersect<Fast, NP, NS>(sc, x, l, tne);        // :420 shadow ray
-                if (idne == np + i) {
-                    float omega = (2.0f * kPi) * (1.0f - cos_a_max);      // :421
-                    accrad = accrad + ((divs<Fast>(accmat, kPi) * dm::gmax(dot(l, nl), 0.0f)) * le) * omega;   // :422
-                }
-            }
-            float r1 = (2.0f * kPi) * rnd.x, r2 = rnd.y, r2s = dm::fsqrt<Fast>(r2);   // :426
-            v3 w = nl;
-            v3 u = normalize<Fast>(cross((__builtin_fabsf(w.x) > 0.1f ? v3{0, 1, 0} : v3{1, 0, 0}), w));   // :427
-            v3 v = cross(w, u);
-            float s1, c1;
-            dm::sincos_angle<Fast>(r1, rnd.x, s1, c1);
-            rd = normalize<Fast>(((u * c1) * r2s + (v * s1) * r2s) + w * dm::fsqrt<Fast>(1.0f - r2));   // :428
-            ro = x;
-            emissive = 0.0f;                                              // :429
-        } else if (mat == 2) {                                            // :432 mirror
-            rd = reflect(rd, n);
-            ro = x;
-            emissive = 1.0f;
-        } else if (mat == 3) {                                            // :437 glass
-            bool into = (n.x == nl.x) && (n.y == nl.y) && (n.z == nl.z);  // :438
-            const float nc = 1.0f, nt = 1.5f;
-            float nnt = into ? dm::fdiv<Fast>(nc, nt) : dm::fdiv<Fast>(nt, nc);   // :439
-            float ddn = dot(rd, nl);
-            float cos2t = 1.0f - (nnt * nnt) * (1.0f - ddn * ddn);        // :440
-            v3 refl = reflect(rd, n);
-            if (cos2t >= 0.0f) {
-                float k = (into ? 1.0f : -1.0f) * (ddn * nnt + dm::fsqrt<Fast>(cos2t));
-                v3 tdir = normalize<Fast>(rd * nnt - n * k);              // :441
-                float aa = nt - nc, bb = nt + nc;
-                float R0 = dm::fdiv<Fast>(aa * aa, bb * bb);              // :442
-                float c = 1.0f - (into ? -ddn : dot(tdir, n));
-                float Re = R0 + (((((1.0f - R0) * c) * c) * c) * c) * c;  // :443
-                float Tr = 1.0f - Re;
-                float P = 0.25f + 0.5f * Re;
-                float RP = dm::fdiv<Fast>(Re, P), TP = dm::fdiv<Fast>(Tr, 1.0f - P);
-                bool pick_refl = rnd.x < P;
-                rd = select(pick_refl, refl, tdir);                       // :444
-                accmat = accmat * (pick_refl ? RP : TP);                  // :445
-            } else {
-                rd = refl;                                                // :446
-            }
-            ro = x;
-            emissive = 1.0f;                                              // :447
-        }
-    }
-    return accrad;
-}
-
-template <bool Fast, int NP, int NS>
-__global__ void __launch_bounds__(256) pathtrace_kernel(PTArgs a) {
-    __shared__ float lds_obj[(kMaxPlanes + kMaxSpheres) * 12];
-    {
-        const uint32_t count = (a.scene.n_planes + a.scene.n_spheres) * 12u;
-        for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) lds_obj[i] = a.scene.obj[i];
-    }
-    __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t gx = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t ty = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);   // tile-local storage row
-    const uint32_t r = tile_row_to_storage(ty, a.row_begin, a.row_block, a.row_stride);
-    if (gx >= a.W || r >= a.row_end) return;                                   // pathTracer.comp:348
-    const uint32_t gy = a.H - 1u - r;                                          // :349 gid = (H-1-y)*W + x
-    const size_t idx = (size_t)ty * a.W + gx;
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (a.sample_begin > 0) acc = a.out[idx];   // progressive continuation (samps.x protocol)
-    const float fspp = (float)a.spp;
-    for (uint32_t s = a.sample_begin; s < a.sample_end; s++) {
-        v3 rad = trace_sample<Fast, NP, NS>(a, lds_obj, gx, gy, s);
-        if (s == 0) acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                 // :451
-        v3 q = divs<Fast>(rad, fspp);                                          // :452
-        acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += 0.0f;
-        if (s == a.spp - 1u) {                                                 // :453
-            acc.x = dm::fpow<Fast>(dm::gmin(dm::gmax(acc.x, 0.0f), 1.0f), 0.45f) * 255.0f + 0.5f;
-            acc.y = dm::fpow<Fast>(dm::gmin(dm::gmax(acc.y, 0.0f), 1.0f), 0.45f) * 255.0f + 0.5f;
-            acc.z = dm::fpow<Fast>(dm::gmin(dm::gmax(acc.z, 0.0f), 1.0f), 0.45f) * 255.0f + 0.5f;
-        }
-    }
-    a.out[idx] = acc;
-}
 
 // ---- host-side IEEE fp32 helpers for the camera basis (same operation order as the kernels) ------
 inline v3 h_add(v3 a, v3 b) { return v3{a.x + b.x, a.y + b.y, a.z + b.z}; }
@@ -269,6 +18,41 @@ inline v3 h_muls(v3 a, float s) { return v3{a.x * s, a.y * s, a.z * s}; }
 inline float h_dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 inline v3 h_cross(v3 a, v3 b) { return v3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
 inline v3 h_normalize(v3 a) { return h_muls(a, 1.0f / sqrtf(h_dot(a, a))); }
+
+// Slab specialisation is exact only when (see pathtrace_kernel.h, intersect()):
+//   * there are exactly 6 planes and 3 spheres (the shape the specialised kernels are unrolled for),
+//   * every plane normal is +-1 along one axis and +-0 along the others, with a non-zero offset w,
+//   * no two planes share (axis, sign), and
+//   * plane indices are grouped by axis in x, y, z order, so visiting the axes in that order compares
+//     candidates in the reference's plane-index order (ties on `d < t` keep the earlier plane).
+bool analyse_slabs(const float* planes, uint32_t n_planes, uint32_t n_spheres, pt::SceneArgs& sc) {
+    for (int a = 0; a < 3; a++) { sc.slab_id_pos[a] = sc.slab_id_neg[a] = -1; sc.slab_w_pos[a] = sc.slab_w_neg[a] = 0.0f; }
+    if (n_planes != 6 || n_spheres != 3) return false;
+    int axis_of[6];
+    for (uint32_t i = 0; i < n_planes; i++) {
+        const float* pl = planes + 12 * i;
+        int axis = -1;
+        for (int a = 0; a < 3; a++) {
+            if (pl[a] == 1.0f || pl[a] == -1.0f) { if (axis >= 0) return false; axis = a; }
+            else if (pl[a] != 0.0f) return false;   // also rejects NaN
+        }
+        if (axis < 0 || pl[3] == 0.0f || !std::isfinite(pl[3])) return false;
+        axis_of[i] = axis;
+        if (pl[axis] > 0.0f) { if (sc.slab_id_pos[axis] >= 0) return false; sc.slab_id_pos[axis] = (int)i; sc.slab_w_pos[axis] = pl[3]; }
+        else { if (sc.slab_id_neg[axis] >= 0) return false; sc.slab_id_neg[axis] = (int)i; sc.slab_w_neg[axis] = pl[3]; }
+    }
+    for (uint32_t i = 1; i < n_planes; i++)
+        if (axis_of[i] < axis_of[i - 1]) return false;   // indices must be grouped x, then y, then z
+    return true;
+}
+
+// Sample-parallel width: enough waves to keep 256 CUs x ~28 wave slots busy with a short tail.
+int choose_S(uint64_t pixels, uint32_t samples) {
+    const uint64_t target_waves = 65536;
+    if (pixels / 64 >= target_waves || samples < 4) return 1;
+    if (pixels * 4 / 64 >= target_waves || samples < 16) return 4;
+    return 16;
+}
 
 }  // namespace
 
@@ -280,7 +64,7 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
         return MC_ERR_INVALID_ARGUMENT;
     if (p->math_mode != MC_PT_MATH_STRICT && p->math_mode != MC_PT_MATH_FAST) return MC_ERR_INVALID_ARGUMENT;
     if (p->row_stride && (!p->row_block || p->row_block > p->row_stride)) return MC_ERR_INVALID_ARGUMENT;
-    if (n_planes > (uint32_t)kMaxPlanes || n_spheres > (uint32_t)kMaxSpheres) {
+    if (n_planes > (uint32_t)pt::kMaxPlanes || n_spheres > (uint32_t)pt::kMaxSpheres) {
         set_error_detail("scene exceeds the on-chip scene store (16 planes + 16 spheres)");
         return MC_ERR_UNSUPPORTED;
     }
@@ -307,17 +91,14 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
         v3 e{sp[4], sp[5], sp[6]};
         if (h_dot(e, e) > 0.0f) a.scene.emissive_mask |= 1u << i;
     }
+    const bool slab = analyse_slabs(planes, n_planes, n_spheres, a.scene) && !(p->flags & MC_PT_GENERIC_KERNEL);
     const uint32_t rows = tile_rows(p->row_begin, p->row_end, a.row_block, a.row_stride);
-    dim3 grid((p->width + 15u) / 16u, (rows + 15u) / 16u), block(256);
-    const bool fast = p->math_mode == MC_PT_MATH_FAST;
-    const bool def = n_planes == 6 && n_spheres == 3;   // the reference scene's shape: fully unrolled loops
-    if (def) {
-        if (fast) hipLaunchKernelGGL((pathtrace_kernel<true, 6, 3>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((pathtrace_kernel<false, 6, 3>), grid, block, 0, s, a);
-    } else {
-        if (fast) hipLaunchKernelGGL((pathtrace_kernel<true, -1, -1>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((pathtrace_kernel<false, -1, -1>), grid, block, 0, s, a);
-    }
+    int S = (int)((p->flags >> 8) & 0xffu);   // MC_PT_FORCE_S(s)
+    if (S == 0) S = choose_S((uint64_t)rows * p->width, p->sample_end - p->sample_begin);
+    if (S != 1 && S != 4 && S != 16) return MC_ERR_INVALID_ARGUMENT;
+    int rc = p->math_mode == MC_PT_MATH_FAST ? pt::launch_fast(a, slab ? 1 : 0, S, rows, s)
+                                             : pt::launch_strict(a, slab ? 1 : 0, S, rows, s);
+    if (rc) return rc;
     MC_HIP_TRY(hipGetLastError());
     return MC_OK;
 }

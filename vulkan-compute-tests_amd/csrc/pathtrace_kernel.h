@@ -1,0 +1,352 @@
+// Path tracer device code for gfx950 (MI355X) — included by pathtrace_fast.hip / pathtrace_strict.hip.
+//
+// Replaces shaders/pathTracer.comp:343-458 AND the host-side sample loop that records `spp`
+// dispatches (src/pathtracerApp.h:358-378): the whole [sample_begin, sample_end) range of a pixel
+// runs inside one launch, the accumulator lives in registers, and the 16-B storage-buffer entry is
+// written once (the reference re-reads and re-writes it every sample through host-visible memory).
+//
+// Parity rules:
+//  * samples are accumulated in sample order, `acc += accrad / spp` per sample (pathTracer.comp:451-452);
+//  * rand01 is the reference's stateless integer hash, bit-exact (pathTracer.comp:107-110);
+//  * every fp32 expression keeps the GLSL source order, unfused (built -ffp-contract=off);
+//  * strict mode uses IEEE divide/sqrt and the explicit mc_math.h algorithms for sin/cos/pow, which
+//    makes the output buffer bit-identical to the CPU oracle; fast mode uses the gfx950 hardware
+//    approximations and is compared under a stated tolerance.
+//
+// MI355X mapping:
+//  * SAMPLE-PARALLEL LANES.  A wave64 owns 64/S pixels x S consecutive samples (S = 1,4,16).  The S
+//    lanes of a pixel trace samples base+0..base+S-1 concurrently; after each round their radiances
+//    are folded into the pixel accumulator IN SAMPLE ORDER through cross-lane reads, so the fp32 sum
+//    is the same sequence of additions as the one-thread-per-pixel loop.  S is chosen on the host so
+//    that even a 900x600 image yields >10^5 short waves: the 256 CUs stay full and the tail vanishes
+//    (with S = 1 that image is only 8.4k long waves against ~7k resident wave slots).
+//  * Scene constants arrive in the kernel-argument segment: uniform accesses in the intersection
+//    loops become scalar loads / SGPR operands; the per-lane material fetch by hit index reads a copy
+//    staged in LDS at kernel start.
+//  * SLAB SPECIALISATION (exact).  When the host finds that every plane normal is +-1 along one axis
+//    and 0 elsewhere (the reference scene is an axis-aligned box), dot(d,n) is exactly +-d[axis], at
+//    most one of the two planes of an axis can face the ray, and the six plane tests collapse into
+//    three — same quotients, same comparison order, bit-identical hit records (see intersect()).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mc_internal.h"
+#include "mc_math.h"
+
+namespace mc {
+namespace pt {
+
+constexpr int kMaxPlanes = 16;
+constexpr int kMaxSpheres = 16;
+
+struct v3 {
+    float x, y, z;
+};
+
+// Scene in the order the kernels consume it.  obj[] keeps the reference's 12-float records
+// (planes first, then spheres) for the per-lane material fetch; r2[] caches radius*radius (the fp32
+// product the shader computes at pathTracer.comp:318, evaluated once on the host in fp32).
+struct SceneArgs {
+    uint32_t n_planes, n_spheres;
+    uint32_t emissive_mask;   // bit i set <=> dot(spheres[i].e, spheres[i].e) > 0  (pathTracer.comp:407)
+    uint32_t pad;
+    float obj[(kMaxPlanes + kMaxSpheres) * 12];
+    float r2[kMaxSpheres];
+    // slab form of axis-aligned planes (valid only for the Slab kernels): per axis the plane whose normal
+    // is +e_axis ("pos") and -e_axis ("neg"): offset w and plane index, index < 0 when absent.
+    float slab_w_pos[3], slab_w_neg[3];
+    int32_t slab_id_pos[3], slab_id_neg[3];
+};
+
+struct PTArgs {
+    uint32_t W, H, spp, sample_begin, sample_end, max_depth, row_begin, row_end, row_block, row_stride;
+    // camera basis (pathTracer.comp:352-353,360), evaluated once on the host with the same IEEE ops
+    v3 cam_o, cam_d, cx, cy, lc;
+    float4* __restrict__ out;   // tile-local storage rows
+    SceneArgs scene;
+};
+
+__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return v3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return v3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ v3 operator*(v3 a, v3 b) { return v3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ v3 operator*(v3 a, float s) { return v3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ v3 operator-(v3 a) { return v3{-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ float dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// GLSL cross: (a.y*b.z - b.y*a.z, a.z*b.x - b.z*a.x, a.x*b.y - b.x*a.y)
+__device__ __forceinline__ v3 cross(v3 a, v3 b) {
+    return v3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
+}
+template <bool Fast> __device__ __forceinline__ v3 normalize(v3 a) { return a * dm::inversesqrt<Fast>(dot(a, a)); }
+template <bool Fast> __device__ __forceinline__ v3 divs(v3 a, float s) {
+    return v3{dm::fdiv<Fast>(a.x, s), dm::fdiv<Fast>(a.y, s), dm::fdiv<Fast>(a.z, s)};
+}
+// reflect(I,N) = I - 2*dot(N,I)*N
+__device__ __forceinline__ v3 reflect(v3 I, v3 N) { return I - N * (2.0f * dot(N, I)); }
+__device__ __forceinline__ v3 select(bool c, v3 a, v3 b) { return v3{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
+__device__ __forceinline__ float comp(v3 a, int axis) { return axis == 0 ? a.x : (axis == 1 ? a.y : a.z); }
+
+// rand01 — pathTracer.comp:107-110 (float(0xffffffffU) rounds to 2^32: the scale is exactly 2^-32)
+__device__ __forceinline__ v3 rand01(uint32_t x, uint32_t y, uint32_t z) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        uint32_t nx = ((x >> 8) ^ y) * 1103515245u;
+        uint32_t ny = ((y >> 8) ^ z) * 1103515245u;
+        uint32_t nz = ((z >> 8) ^ x) * 1103515245u;
+        x = nx; y = ny; z = nz;
+    }
+    const float s = 2.3283064365386963e-10f;   // 2^-32
+    return v3{(float)x * s, (float)y * s, (float)z * s};
+}
+
+constexpr float kEps = 1e-4f, kTriEps = 1e-7f, kInf = 1e20f;   // pathTracer.comp:103-105
+constexpr float kPi = 3.141592653589793f;                       // :102
+
+// intersect — pathTracer.comp:112-131 + :316-341.  Returns the hit object id (planes 0..NP-1, spheres
+// NP..NP+NS-1) or -1, and the ray parameter.  NP/NS < 0 select run-time counts.
+template <bool Fast, int NP, int NS, bool Slab>
+__device__ __forceinline__ int intersect(const SceneArgs& sc, v3 o, v3 d, float& t_out) {
+    const int np = NP >= 0 ? NP : (int)sc.n_planes;
+    const int ns = NS >= 0 ? NS : (int)sc.n_spheres;
+    float t = kInf;
+    int id = -1;
+    if (Slab) {
+        // Axis-aligned planes.  For n = s*e_a (s = +-1, other components +-0) and a finite ray:
+        //   denom = dot(d,n) = s*d[a] exactly;  t = (w - dot(o,n)) / denom = (w - s*o[a]) / (s*d[a]).
+        // The "pos" plane faces the ray iff d[a] > triEps, the "neg" plane iff -d[a] > triEps: never both.
+        // pos: (w_pos - o[a]) / d[a];  neg: (w_neg - (-o[a])) / (-d[a]) = (w_neg + o[a]) / |d[a]|.
+        // Axes are visited in plane-index order (host-checked), so `dd < t` resolves ties as the
+        // reference's loop over planes does.  A NaN ray fails every test in both formulations.
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float da = comp(d, a), oa = comp(o, a);
+            const bool pos = da > 0.0f;
+            const float den = __builtin_fabsf(da);
+            const float num = pos ? (sc.slab_w_pos[a] - oa) : (sc.slab_w_neg[a] + oa);
+            const int pid = pos ? sc.slab_id_pos[a] : sc.slab_id_neg[a];
+            const float dd = dm::fdiv<Fast>(num, den);
+            if (den > kTriEps && pid >= 0 && dd < t) { t = dd; id = pid; }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < np; i++) {
+            const float* pl = sc.obj + 12 * i;
+            v3 n{pl[0], pl[1], pl[2]};
+            float denom = dot(d, n);                                         // :118
+            if (denom > kTriEps) {                                           // :119
+                float dd = dm::fdiv<Fast>(pl[3] - dot(o, n), denom);         // :120
+                if (dd < t) { t = dd; id = i; }                              // :121
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < ns; i++) {
+        const float* sp = sc.obj + 12 * (np + i);
+        v3 oc = v3{sp[0], sp[1], sp[2]} - o;                                 // :317
+        float b = dot(oc, d);                                                // :318
+        float det = (b * b - dot(oc, oc)) + sc.r2[i];
+        if (!(det < 0.0f)) {                                                 // :319
+            float sq = dm::fsqrt<Fast>(det);
+            float dd = b - sq;                                               // :322,324
+            if (dd <= kEps) {                                                // :325
+                dd = b + sq;                                                 // :323,326
+                if (dd <= kEps) dd = kInf;                                   // :327
+            }
+            if (dd < t) { t = dd; id = np + i; }                             // :333
+        }
+    }
+    t_out = t;
+    return (t < kInf) ? id : -1;                                             // :336
+}
+
+// One sample: returns accrad (pathTracer.comp:356-449).
+template <bool Fast, int NP, int NS, bool Slab>
+__device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restrict__ lds_obj, uint32_t gx, uint32_t gy,
+                                           uint32_t samp) {
+    const SceneArgs& sc = a.scene;
+    const int np = NP >= 0 ? NP : (int)sc.n_planes;
+    const int ns = NS >= 0 ? NS : (int)sc.n_spheres;
+    // -- sample sensor (:357-362)
+    v3 r0 = rand01(gx, gy, samp);
+    float rnd2x = 2.0f * r0.x, rnd2y = 2.0f * r0.y;
+    float tentx = rnd2x < 1.0f ? dm::fsqrt<Fast>(rnd2x) - 1.0f : 1.0f - dm::fsqrt<Fast>(2.0f - rnd2x);
+    float tenty = rnd2y < 1.0f ? dm::fsqrt<Fast>(rnd2y) - 1.0f : 1.0f - dm::fsqrt<Fast>(2.0f - rnd2y);
+    float stratx = (float)((samp / 2u) % 2u), straty = (float)(samp % 2u);
+    float sx = (dm::fdiv<Fast>((float)gx + 0.5f * ((0.5f + stratx) + tentx), (float)a.W) - 0.5f) * 0.036f;
+    float sy = (dm::fdiv<Fast>((float)gy + 0.5f * ((0.5f + straty) + tenty), (float)a.H) - 0.5f) * 0.024f;
+    v3 spos = (a.cam_o + a.cx * sx) + a.cy * sy;                          // :360
+    v3 accrad{0.0f, 0.0f, 0.0f}, accmat{1.0f, 1.0f, 1.0f};               // :361
+    v3 ro = a.lc, rd = normalize<Fast>(a.lc - spos);                      // :362
+    float emissive = 1.0f;                                                // :365
+
+    for (uint32_t depth = 0; depth < a.max_depth; depth++) {              // :367
+        float t;
+        int id = intersect<Fast, NP, NS, Slab>(sc, ro, rd, t);
+        if (id < 0) break;   // :369 `continue` with an unchanged ray misses again at every later depth: no effect
+        v3 x = ro + rd * t;                                               // :374 (o + t*d: fp32 mul is commutative)
+        const float* obj = lds_obj + 12 * id;                             // per-lane fetch from LDS
+        const bool is_sphere = id >= np;
+        v3 geo{obj[0], obj[1], obj[2]};
+        v3 emi{obj[4], obj[5], obj[6]};
+        v3 col{obj[8], obj[9], obj[10]};
+        int mat = (int)__builtin_floorf(obj[11] + 0.5f);                  // :378/:384
+        v3 n = is_sphere ? normalize<Fast>(x - geo) : geo;                // :381/:387
+        v3 nl = dot(n, rd) < 0.0f ? n : -n;                               // :390
+        accrad = accrad + (accmat * emi) * emissive;                      // :391
+        accmat = accmat * col;                                            // :392
+        v3 rnd = rand01(gx, gy, samp * a.max_depth + depth);              // :393
+        float p = dm::gmax(dm::gmax(col.x, col.y), col.z);               // :394
+        if (depth > 5) {                                                  // :395
+            if (rnd.z >= p) break;                                        // :396
+            accmat = divs<Fast>(accmat, p);                               // :397
+        }
+        if (mat == 1) {                                                   // :400 diffuse
+            for (int i = 0; i < ns; i++) {                                // :403
+                if (!((sc.emissive_mask >> i) & 1u)) continue;            // :407 (uniform)
+                const float* ls = sc.obj + 12 * (np + i);
+                v3 le{ls[4], ls[5], ls[6]};
+                v3 xc = v3{ls[0], ls[1], ls[2]} - x;                      // :408
+                v3 sw = normalize<Fast>(xc);                              // :409
+                v3 su = normalize<Fast>(cross((__builtin_fabsf(sw.x) > 0.1f ? v3{0, 1, 0} : v3{1, 0, 0}), sw));
+                v3 sv = cross(sw, su);
+                float cos_a_max = dm::fsqrt<Fast>(1.0f - dm::fdiv<Fast>(sc.r2[i], dot(xc, xc)));   // :410
+                float cos_a = (1.0f - rnd.x) + rnd.x * cos_a_max;         // :411
+                float sin_a = dm::fsqrt<Fast>(1.0f - cos_a * cos_a);
+                float phi = (2.0f * kPi) * rnd.y;                         // :412
+                float sphi, cphi;
+                dm::sincos_angle<Fast>(phi, rnd.y, sphi, cphi);
+                v3 l = normalize<Fast>(((su * cphi) * sin_a + (sv * sphi) * sin_a) + sw * cos_a);   // :413
+                float tne;
+                int idne = intersect<Fast, NP, NS, Slab>(sc, x, l, tne);  // :420 shadow ray
+                if (idne == np + i) {
+                    float omega = (2.0f * kPi) * (1.0f - cos_a_max);      // :421
+                    accrad = accrad + ((divs<Fast>(accmat, kPi) * dm::gmax(dot(l, nl), 0.0f)) * le) * omega;   // :422
+                }
+            }
+            float r1 = (2.0f * kPi) * rnd.x, r2 = rnd.y, r2s = dm::fsqrt<Fast>(r2);   // :426
+            v3 w = nl;
+            v3 u = normalize<Fast>(cross((__builtin_fabsf(w.x) > 0.1f ? v3{0, 1, 0} : v3{1, 0, 0}), w));   // :427
+            v3 v = cross(w, u);
+            float s1, c1;
+            dm::sincos_angle<Fast>(r1, rnd.x, s1, c1);
+            rd = normalize<Fast>(((u * c1) * r2s + (v * s1) * r2s) + w * dm::fsqrt<Fast>(1.0f - r2));   // :428
+            ro = x;
+            emissive = 0.0f;                                              // :429
+        } else if (mat == 2) {                                            // :432 mirror
+            rd = reflect(rd, n);
+            ro = x;
+            emissive = 1.0f;
+        } else if (mat == 3) {                                            // :437 glass
+            bool into = (n.x == nl.x) && (n.y == nl.y) && (n.z == nl.z);  // :438
+            const float nc = 1.0f, nt = 1.5f;
+            float nnt = into ? dm::fdiv<Fast>(nc, nt) : dm::fdiv<Fast>(nt, nc);   // :439
+            float ddn = dot(rd, nl);
+            float cos2t = 1.0f - (nnt * nnt) * (1.0f - ddn * ddn);        // :440
+            v3 refl = reflect(rd, n);
+            if (cos2t >= 0.0f) {
+                float k = (into ? 1.0f : -1.0f) * (ddn * nnt + dm::fsqrt<Fast>(cos2t));
+                v3 tdir = normalize<Fast>(rd * nnt - n * k);              // :441
+                float aa = nt - nc, bb = nt + nc;
+                float R0 = dm::fdiv<Fast>(aa * aa, bb * bb);              // :442
+                float c = 1.0f - (into ? -ddn : dot(tdir, n));
+                float Re = R0 + (((((1.0f - R0) * c) * c) * c) * c) * c;  // :443
+                float Tr = 1.0f - Re;
+                float P = 0.25f + 0.5f * Re;
+                float RP = dm::fdiv<Fast>(Re, P), TP = dm::fdiv<Fast>(Tr, 1.0f - P);
+                bool pick_refl = rnd.x < P;
+                rd = select(pick_refl, refl, tdir);                       // :444
+                accmat = accmat * (pick_refl ? RP : TP);                  // :445
+            } else {
+                rd = refl;                                                // :446
+            }
+            ro = x;
+            emissive = 1.0f;                                              // :447
+        }
+    }
+    return accrad;
+}
+
+// Wave tile of 64/S pixels: width x height.
+template <int S> struct WaveTile;
+template <> struct WaveTile<1> { static constexpr uint32_t w = 8, h = 8; };
+template <> struct WaveTile<4> { static constexpr uint32_t w = 4, h = 4; };
+template <> struct WaveTile<16> { static constexpr uint32_t w = 2, h = 2; };
+template <> struct WaveTile<64> { static constexpr uint32_t w = 1, h = 1; };
+
+// Pixels covered by one 256-thread block (2 x 2 wave tiles).
+template <int S> constexpr uint32_t block_w() { return 2u * WaveTile<S>::w; }
+template <int S> constexpr uint32_t block_h() { return 2u * WaveTile<S>::h; }
+
+template <bool Fast, int NP, int NS, bool Slab, int S>
+__global__ void __launch_bounds__(256) pathtrace_kernel(PTArgs a) {
+    __shared__ float lds_obj[(kMaxPlanes + kMaxSpheres) * 12];
+    {
+        const uint32_t count = (a.scene.n_planes + a.scene.n_spheres) * 12u;
+        for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) lds_obj[i] = a.scene.obj[i];
+    }
+    __syncthreads();
+    constexpr uint32_t TW = WaveTile<S>::w, TH = WaveTile<S>::h;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t j = lane % (uint32_t)S;          // sample slot of this lane within its pixel
+    const uint32_t pix = lane / (uint32_t)S;        // pixel of this lane within the wave tile
+    const uint32_t gx = blockIdx.x * (2u * TW) + (wave & 1u) * TW + (pix % TW);
+    const uint32_t ty = blockIdx.y * (2u * TH) + (wave >> 1) * TH + (pix / TW);   // tile-local storage row
+    const uint32_t r = tile_row_to_storage(ty, a.row_begin, a.row_block, a.row_stride);
+    const bool valid = gx < a.W && r < a.row_end;                               // pathTracer.comp:348
+    const uint32_t gy = a.H - 1u - (valid ? r : 0u);                            // :349 gid = (H-1-y)*W + x
+    const size_t idx = valid ? (size_t)ty * a.W + gx : 0;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (valid && a.sample_begin > 0) acc = a.out[idx];   // progressive continuation (samps.x protocol); s==0 resets (:451)
+    const float fspp = (float)a.spp;
+    const uint32_t group_base = lane - j;           // first lane of this pixel's group
+    for (uint32_t base = a.sample_begin; base < a.sample_end; base += (uint32_t)S) {
+        const uint32_t s = base + j;
+        v3 q{0.0f, 0.0f, 0.0f};
+        if (valid && s < a.sample_end) {
+            v3 rad = trace_sample<Fast, NP, NS, Slab>(a, lds_obj, gx, gy, s);
+            q = divs<Fast>(rad, fspp);                                          // :452 accrad / samps.y
+        }
+        // fold the round's S samples into the accumulator in sample order (every lane of the group
+        // performs the same additions, so all S copies of acc stay identical)
+        const uint32_t count = min((uint32_t)S, a.sample_end - base);           // wave-uniform
+        if (S == 1) {
+            acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += 0.0f;
+        } else {
+            for (uint32_t k = 0; k < count; k++) {
+                const int src = (int)(group_base + k);
+                acc.x += __shfl(q.x, src); acc.y += __shfl(q.y, src); acc.z += __shfl(q.z, src); acc.w += 0.0f;
+            }
+        }
+    }
+    if (a.sample_end == a.spp) {                                                // :453 after sample spp-1
+        acc.x = dm::fpow<Fast>(dm::gmin(dm::gmax(acc.x, 0.0f), 1.0f), 0.45f) * 255.0f + 0.5f;
+        acc.y = dm::fpow<Fast>(dm::gmin(dm::gmax(acc.y, 0.0f), 1.0f), 0.45f) * 255.0f + 0.5f;
+        acc.z = dm::fpow<Fast>(dm::gmin(dm::gmax(acc.z, 0.0f), 1.0f), 0.45f) * 255.0f + 0.5f;
+    }
+    if (valid && j == 0) a.out[idx] = acc;
+}
+
+// Launch helpers implemented once per math mode (pathtrace_fast.hip / pathtrace_strict.hip).
+// variant: 0 = generic (run-time object counts), 1 = slab-specialised 6 planes + 3 spheres.
+int launch_fast(const PTArgs& a, int variant, int S, uint32_t tile_rows, hipStream_t s);
+int launch_strict(const PTArgs& a, int variant, int S, uint32_t tile_rows, hipStream_t s);
+
+template <bool Fast>
+inline int launch_impl(const PTArgs& a, int variant, int S, uint32_t tile_rows, hipStream_t s) {
+#define MC_PT_LAUNCH(SVAL)                                                                                          \
+    {                                                                                                               \
+        dim3 grid((a.W + block_w<SVAL>() - 1u) / block_w<SVAL>(), (tile_rows + block_h<SVAL>() - 1u) / block_h<SVAL>()); \
+        if (variant == 1) hipLaunchKernelGGL((pathtrace_kernel<Fast, 6, 3, true, SVAL>), grid, dim3(256), 0, s, a);   \
+        else hipLaunchKernelGGL((pathtrace_kernel<Fast, -1, -1, false, SVAL>), grid, dim3(256), 0, s, a);             \
+    }
+    switch (S) {
+        case 1: MC_PT_LAUNCH(1) break;
+        case 4: MC_PT_LAUNCH(4) break;
+        case 16: MC_PT_LAUNCH(16) break;
+        default: return MC_ERR_INVALID_ARGUMENT;
+    }
+#undef MC_PT_LAUNCH
+    return MC_OK;
+}
+
+}  // namespace pt
+}  // namespace mc

@@ -1,0 +1,11 @@
+// Instantiates the MC_PT_MATH_STRICT path tracer kernels (IEEE divide/sqrt + mc_math sin/cos/pow:
+// bit-identical to the CPU oracle).  Split from the fast instantiations so both compile in parallel.
+#include "pathtrace_kernel.h"
+
+namespace mc {
+namespace pt {
+int launch_strict(const PTArgs& a, int variant, int S, uint32_t tile_rows, hipStream_t s) {
+    return launch_impl<false>(a, variant, S, tile_rows, s);
+}
+}  // namespace pt
+}  // namespace mc
