@@ -44,7 +44,6 @@ PEAK_LANE_OPS = 78.6e12             # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (v_ad
 K2 = dict(W=900, H=600, spp=500)
 K1 = dict(W=3200, H=2400, M=1000)
 K4_VIEW = dict(centre=(-0.7436438870371587, 0.13182590420531198), scale=(1e-8, 1e-8 * 2.0 / 3.0))
-ROW_BLOCK = 16
 
 
 def parse():
@@ -71,7 +70,9 @@ def main():
     import torch.distributed as dist
 
     import __graft_entry__ as entry
-    B = entry.load_package().bindings
+    pkg = entry.load_package()
+    B, S = pkg.bindings, pkg.sharding
+    ROW_BLOCK = S.ROW_BLOCK
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -102,10 +103,7 @@ def main():
         W, Hbase, spp = args.width or K2["W"], args.height or K2["H"], args.spp or K2["spp"]
         H = Hbase * n
         math_mode = B.PT_MATH_FAST if args.math == "fast" else B.PT_MATH_STRICT
-        p = B.pathtrace_params(W, H, spp, math_mode=math_mode, row_begin=rank * ROW_BLOCK, row_end=H,
-                               row_block=ROW_BLOCK if n > 1 else 0, row_stride=ROW_BLOCK * n if n > 1 else 0)
-        if n == 1:
-            p.row_begin, p.row_end = 0, H
+        p = S.shard(B.pathtrace_params(W, H, spp, math_mode=math_mode), rank, n)
         units_per_step = W * H * spp                         # samples
         flops_per_unit = FLOPS_PER_SAMPLE_PT
         metric, unit = "path-traced samples/s", "samples/s"
@@ -114,27 +112,20 @@ def main():
         W, Hbase, M = args.width or K1["W"], args.height or K1["H"], K1["M"]
         H = Hbase * n
         ds = wl == "mandelbrot_ds"
-        kw = dict(max_iter=M, row_begin=rank * ROW_BLOCK, row_end=H, row_block=ROW_BLOCK if n > 1 else 0,
-                  row_stride=ROW_BLOCK * n if n > 1 else 0)
+        kw = dict(max_iter=M)
         if ds:
             kw.update(precision=B.PRECISION_DS, centre=K4_VIEW["centre"], scale=K4_VIEW["scale"])
-        p = B.mandelbrot_params(W, H, **kw)
-        if n == 1:
-            p.row_begin, p.row_end = 0, H
+        p = S.shard(B.mandelbrot_params(W, H, **kw), rank, n)
         units_per_step = None                                # pixel-iters: data dependent, counted after the run
         flops_per_unit = FLOPS_PER_PIXEL_ITER_DS if ds else FLOPS_PER_PIXEL_ITER_F32
         metric, unit = "Mandelbrot pixel-iters/s", "pixel-iters/s"
         workload_name = f"mandelbrot{'_ds' if ds else ''} {W}x{H} M{M}"
 
     rows_local = B.tile_rows(p)
-    rows_padded = int(B.lib().mc_tile_rows(0, H, ROW_BLOCK, ROW_BLOCK * n)) if n > 1 else rows_local
+    rows_padded = S.padded_tile_rows(H, n) if n > 1 else rows_local
     tile = torch.zeros((rows_padded, W, 4), dtype=torch.float32, device="cuda")
     iters_t = torch.zeros((rows_padded, W), dtype=torch.int32, device="cuda") if wl != "pathtrace" else None
-    gathered = full = None
-    if n > 1 and rank == 0:
-        gathered = [torch.empty_like(tile) for _ in range(n)]
-        gathered_flat = torch.empty((n, rows_padded, W, 4), dtype=torch.float32, device="cuda")
-        full = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    full = torch.empty((H, W, 4), dtype=torch.float32, device="cuda") if n > 1 and rank == 0 else None
 
     ev_k0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev_k1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -149,11 +140,9 @@ def main():
         if i is not None:
             ev_k1[i].record()
         if n > 1:
-            dist.gather(tile, gathered if rank == 0 else None, dst=0)
+            gathered = S.gather_tiles(tile, rank, n)          # RCCL gather of the fp32 tiles to rank 0
             if rank == 0:
-                torch.stack(gathered, out=gathered_flat)
-                ctx.deinterleave_rows_device(gathered_flat.data_ptr(), W, H, n, ROW_BLOCK, rows_padded, 16,
-                                             full.data_ptr(), stream=stream)
+                S.assemble_device(ctx, gathered, W, H, n, full, stream=stream)
 
     def fence():
         if n > 1:

@@ -1,0 +1,158 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads without a GPU and exports every symbol
+include/mc_compute.h declares; POD layouts match the ctypes mirrors; argument validation and error
+strings work; the host helpers (PNG writer, x86 cast, tiling arithmetic) are correct.  No compute calls."""
+import ctypes as C
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import REFERENCE, ROOT
+
+
+def test_library_exports_every_declared_symbol(B):
+    L = B.lib()
+    names = B.declared_symbols()
+    assert len(names) >= 25
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert L.mc_abi_version() == 1
+
+
+def test_param_struct_layouts(B, tmp_path):
+    """The header is plain C (gcc -std=c99 compiles it) and the ctypes mirrors have the compiler's layout."""
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mc_compute.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mc_mandelbrot_params),'
+                   'offsetof(mc_mandelbrot_params,k_color), offsetof(mc_mandelbrot_params,row_begin),'
+                   'offsetof(mc_mandelbrot_params,flags), sizeof(mc_pathtrace_params),'
+                   'offsetof(mc_pathtrace_params,math_mode), offsetof(mc_pathtrace_params,row_block));return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    mine = [C.sizeof(B.MandelbrotParams), B.MandelbrotParams.k_color.offset, B.MandelbrotParams.row_begin.offset,
+            B.MandelbrotParams.flags.offset, C.sizeof(B.PathtraceParams), B.PathtraceParams.math_mode.offset,
+            B.PathtraceParams.row_block.offset]
+    assert got == mine == [88, 48, 64, 80, 48, 40, 32]
+
+
+def test_defaults_match_the_reference(B):
+    p = B.mandelbrot_params(2000, 2000)
+    assert (p.width, p.height, p.max_iter, p.precision) == (2000, 2000, 128, 0)         # main.cpp:20, mandelbrot.comp:40
+    assert (p.centre_x_hi, p.centre_y_hi) == (np.float32(-0.445), 0.0)                  # mandelbrot.comp:38
+    assert p.scale_x_hi == np.float32(2.34) == np.float32(2.0 + 1.7 * 0.2)
+    assert list(p.k_color) == [np.float32(0.1), np.float32(0.7), np.float32(0.6), 0.0]  # mandelbrotApp.h:139
+    q = B.pathtrace_params(900, 600, 500)
+    assert (q.width, q.height, q.spp, q.sample_begin, q.sample_end, q.max_depth) == (900, 600, 500, 0, 500, 12)
+    planes, spheres = B.default_scene()
+    assert planes.shape == (72,) and spheres.shape == (36,)
+    assert list(planes[:4]) == [-1.0, 0.0, 0.0, np.float32(2.6)] and spheres[16 + 12 - 4] == 0.0
+    assert spheres[2 * 12 + 1] == np.float32(1.6) and list(spheres[2 * 12 + 4:2 * 12 + 7]) == [100, 100, 100]
+
+
+def test_colour_lut_host_function_matches_oracle(B, O):
+    for M, kc in ((128, (0.1, 0.7, 0.6, 0.0)), (1000, (0.9, 0.1, 0.3, 0.0))):
+        lut = np.empty((M + 1, 4), np.float32)
+        kcf = (C.c_float * 4)(*kc)
+        assert B.lib().mc_mandelbrot_colour_lut(M, kcf, lut.ctypes.data_as(C.c_void_p)) == 0
+        f, _ = O.mandel_lut(M, np.array(kc, np.float32))
+        assert np.array_equal(lut.view(np.uint32), f.view(np.uint32))
+
+
+def test_tile_rows_arithmetic(B):
+    L = B.lib()
+    assert L.mc_tile_rows(0, 600, 0, 0) == 600 and L.mc_tile_rows(5, 17, 0, 0) == 12
+    for H in (600, 601, 70, 16, 5):
+        for n in (1, 2, 3, 8):
+            blk = 16
+            tot = 0
+            for rank in range(n):
+                rows = [r for r in range(H) if (r // blk) % n == rank]
+                got = L.mc_tile_rows(rank * blk, H, blk, n * blk) if rank * blk < H else 0
+                assert got == len(rows), (H, n, rank)
+                tot += got
+            assert tot == H
+
+
+def test_error_strings_and_argument_validation_without_gpu(B):
+    L = B.lib()
+    assert L.mc_error_string(0) == b"ok" and b"invalid" in L.mc_error_string(1) and b"device" in L.mc_error_string(2)
+    n = C.c_int(-1)
+    rc = L.mc_device_count(C.byref(n))
+    assert rc in (0, 2)
+    assert L.mc_device_count(None) == 1
+    assert L.mc_mandelbrot_default_params(1, 1, None) == 1
+    assert L.mc_context_synchronize(None) == 1
+    assert L.mc_mandelbrot_render(None, None, None, None) == 1
+    assert L.mc_pathtrace_render(None, None, None, 0, None, 0, None) == 1
+    if rc == 2 or n.value == 0:   # CPU-only container: creating a context must fail loudly, never fall back
+        h = C.c_void_p()
+        assert L.mc_context_create(0, C.byref(h)) == 2 and not h
+        with pytest.raises(B.McError):
+            B.Context(0)
+
+
+# ---- host helpers -------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def hostutil(B):
+    path = os.path.join(os.path.dirname(B.LIB_PATH), "libmc_hostutil.so")
+    H = C.CDLL(path)
+    H.mcu_png_encode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_size_t)]
+    H.mcu_free.argtypes = [C.c_void_p]
+    H.mcu_float_to_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    return H
+
+
+def _encode(H, img):
+    h, w = img.shape[:2]
+    out, n = C.POINTER(C.c_ubyte)(), C.c_size_t(0)
+    assert H.mcu_png_encode(img.ctypes.data_as(C.c_void_p), w, h, C.byref(out), C.byref(n)) == 0
+    data = C.string_at(out, n.value)
+    H.mcu_free(out)
+    return data
+
+
+def test_png_writer_round_trips(hostutil, O):
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    opaque = rng.integers(0, 256, size=(37, 53, 4), dtype=np.uint8); opaque[..., 3] = 255
+    translucent = rng.integers(0, 256, size=(5, 3, 4), dtype=np.uint8)
+    _, lut_u8 = O.mandel_lut(128)
+    mandel = np.ascontiguousarray(lut_u8[O.mandelbrot_iters(200, 120, 128)])
+    for img in (opaque, translucent, mandel, np.full((1, 1, 4), 255, np.uint8)):
+        data = _encode(hostutil, np.ascontiguousarray(img))
+        assert data[:8] == b"\x89PNG\r\n\x1a\n"
+        dec = np.asarray(Image.open(io.BytesIO(data)).convert("RGBA"))
+        assert np.array_equal(dec, img)
+        if O.ref_lodepng() is not None:      # the reference's own decoder reads our file to the same pixels
+            assert np.array_equal(O.ref_png_decode(data), img)
+    # chunk CRCs are valid
+    pos = 8
+    while pos < len(data):
+        ln = int.from_bytes(data[pos:pos + 4], "big")
+        assert zlib.crc32(data[pos + 4:pos + 8 + ln]) == int.from_bytes(data[pos + 8 + ln:pos + 12 + ln], "big")
+        pos += 12 + ln
+
+
+def test_host_x86_cast_matches_oracle(hostutil, O):
+    v = np.concatenate([np.random.default_rng(1).uniform(-600, 600, 5000), [np.nan, np.inf, -np.inf, 2.2e9, -2.2e9, 255.999, -0.999]]).astype(np.float32)
+    out = np.empty(v.size, np.uint8)
+    hostutil.mcu_float_to_u8(v.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), v.size)
+    quad = np.zeros((v.size, 4), np.float32); quad[:, 0] = v
+    assert np.array_equal(out, O.float_to_rgba8(quad, 1.0)[:, 0])
+
+
+def test_apps_report_missing_device_like_the_reference(B):
+    """main.cpp:35-38: a std::runtime_error is printed and the process exits with EXIT_FAILURE.  On the CPU-only
+    container the apps have no device: they must say so and fail (no silent fallback)."""
+    n = C.c_int(0)
+    if B.lib().mc_device_count(C.byref(n)) == 0 and n.value > 0:
+        pytest.skip("a GPU is present: covered by the gpu tests")
+    bindir = os.path.join(os.path.dirname(os.path.dirname(B.LIB_PATH)), "bin")
+    for exe, args in (("pathtracer", ["1", "16"]), ("mandelbrot", ["--width", "16", "--height", "16"])):
+        r = subprocess.run([os.path.join(bindir, exe)] + args, capture_output=True, text=True, cwd="/tmp")
+        assert r.returncode == 1
+        assert "starting main!" in r.stdout and "could not find a device" in r.stdout

@@ -1,0 +1,96 @@
+"""world_size-2 test of the N > 1 path on CPU (gloo): the sharding helpers bench.py uses, with the oracle
+standing in for the renderer.  Checks that interleaved row-block tiles rendered independently, gathered to
+rank 0 and re-assembled equal the single-process image bit for bit, for both hot paths."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _deinterleave_numpy(gathered, H, n, block):
+    """numpy mirror of deinterleave_rows_kernel (csrc/postprocess.hip): storage row r <- tile t, tile row k*B + j."""
+    out = np.empty((H,) + gathered.shape[2:], gathered.dtype)
+    for r in range(H):
+        blk, j = divmod(r, block)
+        t, k = blk % n, blk // n
+        out[r] = gathered[t, k * block + j]
+    return out
+
+
+def _worker(rank, world, port, W, H, q):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    S = entry.load_package().sharding
+    B = entry.load_package().bindings
+    O = entry.load_oracle()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        padded = S.padded_tile_rows(H, world)
+        rows = S.rank_rows(H, rank, world)
+        # the C-ABI's own tile arithmetic agrees with the Python helper
+        p = S.shard(B.pathtrace_params(W, H, 4), rank, world)
+        assert B.tile_rows(p) == len(rows)
+        results = {}
+        for name in ("mandelbrot", "pathtrace"):
+            if name == "mandelbrot":
+                tile = np.stack([O.mandelbrot_iters(W, H, 100, row_begin=r, row_end=r + 1, nthreads=1)[0] for r in rows]).astype(np.int32)
+            else:
+                tile = np.concatenate([O.pathtrace(W, H, 4, math_mode=O.MATH_MC, row_begin=r, row_end=r + 1, nthreads=1) for r in rows])
+            pad = np.zeros((padded,) + tile.shape[1:], tile.dtype)
+            pad[:len(rows)] = tile
+            g = S.gather_tiles(torch.from_numpy(pad), rank, world)
+            if rank == 0:
+                results[name] = _deinterleave_numpy(g.numpy(), H, world, S.ROW_BLOCK)
+        dist.barrier()
+        if rank == 0:
+            q.put(results)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H", [70, 64])
+def test_two_rank_sharded_render_equals_single(O, B, H):
+    W, world = 24, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert np.array_equal(res["mandelbrot"], O.mandelbrot_iters(W, H, 100).astype(np.int32))
+    full = O.pathtrace(W, H, 4, math_mode=O.MATH_MC)
+    assert np.array_equal(res["pathtrace"].view(np.uint32), full.view(np.uint32))
+
+
+def test_sharding_helpers(B):
+    import __graft_entry__ as entry
+    S = entry.load_package().sharding
+    for H in (600, 601, 16, 5):
+        for n in (1, 2, 4, 8):
+            owned = sorted(sum((S.rank_rows(H, r, n) for r in range(n)), []))
+            assert owned == list(range(H))
+            assert S.padded_tile_rows(H, n) == max(len(S.rank_rows(H, r, n)) for r in range(n))
+    p = S.shard(B.mandelbrot_params(100, 600), 3, 8)
+    assert (p.row_begin, p.row_end, p.row_block, p.row_stride) == (48, 600, 16, 128)
+    p = S.shard(B.mandelbrot_params(100, 600), 0, 1)
+    assert (p.row_begin, p.row_end, p.row_block, p.row_stride) == (0, 600, 0, 0)
+    with pytest.raises(RuntimeError):
+        S.assemble_device(None, torch.zeros(1, 2, 2, 4), 2, 2, 1, torch.zeros(2, 2, 4))

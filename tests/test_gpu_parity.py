@@ -309,3 +309,73 @@ def test_deinterleave_rows_device(ctx, B):
     ctx.deinterleave_rows_device(tiles.data_ptr(), W, H, n, blk, padded, 16, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert torch.equal(out, full)
+
+
+# ---------------------------------------------------------------------------------------------------
+# committed golden fixtures (tests/golden/, generated by make_golden.py) and end-to-end apps
+# ---------------------------------------------------------------------------------------------------
+def test_gpu_against_committed_golden_vectors(ctx, B):
+    import os
+    from conftest import GOLDEN
+    G = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+    _, it = ctx.mandelbrot(B.mandelbrot_params(64, 64, max_iter=128), want_rgba=False)
+    assert np.array_equal(it, G["mandel_ref_64x64_M128"])
+    _, it = ctx.mandelbrot(B.mandelbrot_params(80, 60, max_iter=300, centre=(-0.75, 0.1), scale=(0.01, 0.0075)), want_rgba=False)
+    assert np.array_equal(it, G["mandel_zoom_80x60_M300"])
+    _, it = ctx.mandelbrot(B.mandelbrot_params(48, 32, max_iter=2000, precision=B.PRECISION_DS,
+                                               centre=(-0.7436438870371587, 0.13182590420531198),
+                                               scale=(1e-8, 1e-8 * 2.0 / 3.0)), want_rgba=False)
+    assert np.array_equal(it, G["mandel_ds_48x32_M2000"])
+    assert np.array_equal(bits(ctx.test_rand01(G["rand01_keys"])), bits(G["rand01_out"]))
+    for op in ("add", "sub", "mul", "compare"):
+        assert np.array_equal(bits(ctx.test_ds_op(op, G["ds_a"], G["ds_b"])), bits(G["ds_" + op]))
+    assert np.array_equal(bits(ctx.test_math("sin", G["mc_angles"])), bits(G["mc_sin"]))
+    assert np.array_equal(bits(ctx.test_math("pow045", G["mc_unit"])), bits(G["mc_pow045"]))
+    assert np.array_equal(bits(ctx.pathtrace(B.pathtrace_params(32, 24, 8))), bits(G["pt_mc_32x24_spp8"]))
+    fast = ctx.pathtrace(B.pathtrace_params(32, 24, 8, math_mode=B.PT_MATH_FAST))
+    assert np.abs(fast - G["pt_libm_32x24_spp8"]).mean() < 1.0
+
+
+def test_k2_render_matches_the_reference_image_statistics(ctx, B, O):
+    """BASELINE config K2 (900x600, 500 spp, default scene) end to end on the GPU vs the reference's only artefact,
+    imageForReadme.png, as committed 30x30-pixel block means; plus strict-vs-fast agreement at full size."""
+    import os
+    from conftest import GOLDEN
+    blocks = np.load(os.path.join(GOLDEN, "readme_image_block_means.npy")).astype(np.float64)
+    imgs = {}
+    for mode in (B.PT_MATH_STRICT, B.PT_MATH_FAST):
+        buf = ctx.pathtrace(B.pathtrace_params(900, 600, 500, math_mode=mode))
+        u8 = ctx.convert_rgba8(buf, 1.0, rotate180=True)
+        assert np.array_equal(u8, O.rotate180(O.float_to_rgba8(buf, 1.0).reshape(600, 900, 4), 900, 600))
+        imgs[mode] = u8[..., :3].astype(np.float64)
+        mine = imgs[mode].reshape(20, 30, 30, 30, 3).mean(axis=(1, 3))
+        rmse = np.sqrt(((mine - blocks) ** 2).mean())
+        print("block rmse vs imageForReadme.png:", rmse, "mean", imgs[mode].mean(axis=(0, 1)))
+        assert rmse < 2.5
+        assert np.all(np.abs(imgs[mode].mean(axis=(0, 1)) - blocks.mean(axis=(0, 1))) < 1.5)
+    d = imgs[B.PT_MATH_STRICT] - imgs[B.PT_MATH_FAST]
+    assert np.sqrt((d ** 2).mean()) < 0.5 and np.percentile(np.sqrt((d ** 2).sum(-1)), 99.9) <= 4.0
+
+
+def test_apps_end_to_end(ctx, B, O, tmp_path):
+    """The C++ apps (host/main.cpp): same CLI as the reference (main.cpp:20-25), PNG decodes to the oracle's pixels."""
+    import os
+    import subprocess
+    from PIL import Image
+    bindir = os.path.join(os.path.dirname(os.path.dirname(B.LIB_PATH)), "bin")
+    r = subprocess.run([os.path.join(bindir, "pathtracer"), "6", "32"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    img = np.asarray(Image.open(tmp_path / "pathtracer.png").convert("RGBA"))
+    ref = O.pathtrace(48, 32, 6, math_mode=O.MATH_MC)      # resx = resy*3/2 (main.cpp:24)
+    exp = O.rotate180(O.float_to_rgba8(ref, 1.0).reshape(32, 48, 4), 48, 32)
+    assert np.array_equal(img, exp)
+    r = subprocess.run([os.path.join(bindir, "mandelbrot"), "--width", "320", "--height", "200", "--max-iter", "128"],
+                       capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    img = np.asarray(Image.open(tmp_path / "mandelbrot.png").convert("RGBA"))
+    _, lut_u8 = O.mandel_lut(128)
+    assert np.array_equal(img, lut_u8[O.mandelbrot_iters(320, 200, 128)])
+    # multi-GPU code path of the app on the one GPU present
+    r = subprocess.run([os.path.join(bindir, "mandelbrot"), "--width", "320", "--height", "200", "--gpus", "1", "--out", "m2.png"],
+                       capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0 and np.array_equal(np.asarray(Image.open(tmp_path / "m2.png").convert("RGBA")), img)

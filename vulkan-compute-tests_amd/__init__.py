@@ -7,4 +7,4 @@ Layout:  csrc/  hand-written HIP kernels for gfx950 + the C ABI (include/mc_comp
 
 The directory name contains a hyphen, so import it through `__graft_entry__.load_package()`.
 """
-from . import bindings  # noqa: F401
+from . import bindings, sharding  # noqa: F401

@@ -1,0 +1,26 @@
+// C shim over the host-side helpers (PNG writer, x86 float->u8 cast) so the Python test-suite can call them
+// through ctypes: lib/libmc_hostutil.so.  No GPU code here.
+#include <cstdlib>
+#include <cstring>
+
+#include "pngWriter.h"
+
+extern "C" {
+
+// Encodes RGBA8 into a malloc'ed PNG; caller frees with mcu_free.  Returns 0 on success.
+int mcu_png_encode(const uint8_t* rgba8, uint32_t w, uint32_t h, uint8_t** out, size_t* out_len) {
+    std::vector<uint8_t> png;
+    if (!pngwriter::encode(png, rgba8, w, h).empty()) return 1;
+    *out = (uint8_t*)std::malloc(png.size());
+    if (!*out) return 2;
+    std::memcpy(*out, png.data(), png.size());
+    *out_len = png.size();
+    return 0;
+}
+void mcu_free(void* p) { std::free(p); }
+
+void mcu_float_to_u8(const float* in, uint8_t* out, size_t n) {
+    for (size_t i = 0; i < n; i++) out[i] = x86FloatToU8(in[i]);
+}
+
+}  // extern "C"
