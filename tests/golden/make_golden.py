@@ -4,8 +4,11 @@
 The reference (pjhusky/vulkan-compute-tests) has no tests and no golden vectors, and its
 compute path (GLSL + Vulkan) cannot be built in this environment, so these vectors come from
   (a) the CPU oracle (oracle/, a literal restatement of the shaders) — inputs AND expected outputs, and
-  (b) the reference's only artefact, imageForReadme.png, reduced to 20x30 block means (a statistical pin
-      for the default 900x600 path trace; needs /root/reference at generation time only).
+  (b) the reference's only artefact, imageForReadme.png (the README's 900x600 render), decoded to RGB and
+      also reduced to 20x30 block means; needs /root/reference at generation time only.  It turns out to be
+      a 500-spp render of the default scene with the shader's hash RNG: the oracle and the HIP kernels
+      reproduce >93 % of its pixels exactly and >99 % within +-1 (the rest fork on the rendering GPU's
+      implementation-defined sin/cos/sqrt precision), which pins the path tracer per pixel.
 They pin the oracle against regressions on any machine and let the GPU box (which has no /root/reference)
 compare the HIP path with committed data.
 """
@@ -72,6 +75,10 @@ def main():
         assert img.shape == (600, 900, 3)
         blocks = img.reshape(20, 30, 30, 30, 3).mean(axis=(1, 3)).astype(np.float32)
         np.save(os.path.join(OUT, "readme_image_block_means.npy"), blocks)
+        # the decoded pixels themselves (expected OUTPUT of the reference for 900x600 @ 500 spp, its default run):
+        # a per-pixel known-answer for the whole path-tracer pipeline (sample keys, accumulation order, gamma, u8
+        # conversion, 180-degree rotation).  Stored decoded + deflated, not as the reference's PNG file.
+        np.savez_compressed(os.path.join(OUT, "readme_image_rgb.npz"), rgb=img.astype(np.uint8))
         print("wrote readme_image_block_means.npy", blocks.shape, "mean RGB", img.mean(axis=(0, 1)))
     else:
         print("reference checkout absent: readme_image_block_means.npy not regenerated")

@@ -379,3 +379,18 @@ def test_apps_end_to_end(ctx, B, O, tmp_path):
     r = subprocess.run([os.path.join(bindir, "mandelbrot"), "--width", "320", "--height", "200", "--gpus", "1", "--out", "m2.png"],
                        capture_output=True, text=True, cwd=tmp_path)
     assert r.returncode == 0 and np.array_equal(np.asarray(Image.open(tmp_path / "m2.png").convert("RGBA")), img)
+
+
+def test_k2_render_reproduces_the_reference_image_per_pixel(ctx, B):
+    """Full BASELINE K2 render (both math modes) vs the decoded reference README image (its default 500-spp run)."""
+    import os
+    from conftest import GOLDEN
+    rgb = np.load(os.path.join(GOLDEN, "readme_image_rgb.npz"))["rgb"].astype(np.int32)
+    for mode in (B.PT_MATH_STRICT, B.PT_MATH_FAST):
+        buf = ctx.pathtrace(B.pathtrace_params(900, 600, 500, math_mode=mode))
+        img = ctx.convert_rgba8(buf, 1.0, rotate180=True)[..., :3].astype(np.int32)
+        d = np.abs(img - rgb)
+        exact, within1 = float((d.max(-1) == 0).mean()), float((d.max(-1) <= 1).mean())
+        rmse = float(np.sqrt((d.astype(np.float64) ** 2).mean()))
+        print(f"mode {mode}: exact {exact:.4f} within1 {within1:.4f} rmse {rmse:.3f} max {d.max()}")
+        assert exact > 0.92 and within1 > 0.985 and rmse < 0.8

@@ -222,3 +222,20 @@ def test_reference_lodepng_reencodes_its_own_artefact(O):
     img = O.ref_png_decode(data)
     assert img.shape == (600, 900, 4) and np.all(img[..., 3] == 255)
     assert O.ref_png_encode(img, 900, 600) == data
+
+
+def test_oracle_reproduces_the_reference_image_per_pixel(O):
+    """The reference's README image is its default run (900x600, 500 spp, `./pocketpt-mac`, README.md:24).  A band
+    of 24 storage rows rendered by the oracle at 500 spp, pushed through the host post-process
+    (pathtracerApp.h:202-243), must reproduce the corresponding image rows: >90 % of the pixels exactly and
+    >98 % within +-1 (forks come from the rendering GPU's implementation-defined transcendental precision)."""
+    rgb = np.load(os.path.join(GOLDEN, "readme_image_rgb.npz"))["rgb"].astype(np.int32)   # (600, 900, 3) final image
+    W, H, spp = 900, 600, 500
+    for mode in (O.MATH_LIBM, O.MATH_MC):
+        r0, r1 = 300, 312 if mode == O.MATH_MC else 324
+        buf = O.pathtrace(W, H, spp, math_mode=mode, row_begin=r0, row_end=r1)
+        u8 = O.float_to_rgba8(buf, 1.0).reshape(r1 - r0, W, 4)[..., :3].astype(np.int32)
+        # final image pixel (R, C) = storage pixel (row H-1-R, column W-1-C): the 180-degree rotation
+        exp = rgb[H - r1:H - r0][::-1, ::-1]
+        d = np.abs(u8 - exp).max(-1)
+        assert (d == 0).mean() > 0.90 and (d <= 1).mean() > 0.98, ((d == 0).mean(), (d <= 1).mean())
