@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 # Algorithmic work per unit (frozen from the oracle's per-op counters).
 FLOPS_PER_PIXEL_ITER_F32 = 8        # mandelbrot.comp:43-44 in reuse-optimal form
 FLOPS_PER_PIXEL_ITER_DS = 142       # 3 ds_mul(32) + 4 ds_add/sub(11) + 2
-FLOPS_PER_SAMPLE_PT = 3811.0        # oracle counters, 900x600 default scene (add+mul+div+sqrt+trig+pow)
+FLOPS_PER_SAMPLE_PT = 3809.0        # oracle counters, 900x600 default scene: add 1469 + mul 2072 + div 146 + sqrt 90 + trig 32
 PEAK_FP32_TFLOPS = 157.3            # MI355X vector fp32, FMA counted as 2 (v_pk_fma_f32 only)
 PEAK_LANE_OPS = 78.6e12             # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (v_add/v_mul issue rate)
 
