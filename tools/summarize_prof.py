@@ -25,7 +25,7 @@ def main():
             for r in rows:
                 w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
     summary = {}
-    for kind in ("valu", "hbm"):
+    for kind in ("valu", "hbm", "mix", "busy"):
         files = glob.glob(f"gpurun_out/prof_{tag}_pmc_{kind}/*/*_counter_collection.csv")
         if not files:
             continue
@@ -53,6 +53,15 @@ def main():
             d["gpu_cycles_per_xcd"] = c["GRBM_GUI_ACTIVE"] / 8.0
         if "WRITE_SIZE" in c:
             d["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024.0    # WRITE_SIZE is in KB; exact for 16-B stores (MI355X_MICROARCH.md §HBM)
+        if "SQ_INSTS_VALU_ADD_F32" in c and "GRBM_GUI_ACTIVE" in c:
+            # issue-slot model from tools/valu_microbench.hip: add/mul/int 2 cycles, fma/other 4, transcendental 8
+            other = c["SQ_INSTS_VALU"] - sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32",
+                                                                      "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32"))
+            cyc = 2 * (c["SQ_INSTS_VALU_ADD_F32"] + c["SQ_INSTS_VALU_MUL_F32"]) + 4 * c["SQ_INSTS_VALU_FMA_F32"] \
+                + 8 * c["SQ_INSTS_VALU_TRANS_F32"] + 3 * c["SQ_INSTS_VALU_INT32"] + 3 * other
+            d["valu_other_insts"] = other
+            d["modelled_valu_issue_cycles"] = cyc
+            d["modelled_valu_issue_utilisation"] = cyc / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
         e["derived"] = d
     json.dump(summary, open(out + "_pmc_summary.json", "w"), indent=1)
     print(json.dumps(summary, indent=1))
