@@ -107,6 +107,16 @@ enum {
     MC_PT_GENERIC_KERNEL = 1u << 0 /* never use the axis-aligned-slab specialisation of the plane test */
 };
 #define MC_PT_FORCE_S(s) ((uint32_t)(s) << 8) /* force the sample-parallel width: 1, 4 or 16 (0 = automatic) */
+/* Sphere-test precision branch of pathTracer.comp:132-256.  The reference compiles every variant OUT
+ * (emulateDouble.h.glsl:13-26 are all FALSE) and enables one by hand together with the
+ * TEST_PRECISION_WITH_LARGE_SPHERE_WALLS scene (pathtracerApp.h:11,28-35).  This DOES change results. */
+enum {
+    MC_PT_PREC_F32 = 0,  /* the default build: fp32 test only (pathTracer.comp:316-331)              */
+    MC_PT_PREC_FP64 = 1, /* USE_NATIVE_FP64 (pathTracer.comp:132-143)                                 */
+    MC_PT_PREC_DS = 2,   /* DS_f32_f32 (pathTracer.comp:144-213, emulateDouble.h.glsl:28-223)          */
+    MC_PT_PREC_DF64 = 3  /* DF64_F32_F32 (pathTracer.comp:214-256, emulateDouble.h.glsl:225-356)       */
+};
+#define MC_PT_PRECISION(x) ((uint32_t)(x) << 16)
 
 typedef struct mc_pathtrace_params {
     uint32_t width, height;            /* push constant imgdim (pathtracerApp.h:44-47,58-59)            */
@@ -174,7 +184,8 @@ int mc_multi_pathtrace_render(mc_multi* m, const mc_pathtrace_params* p, const f
 int mc_test_math(mc_context* ctx, int fn, int fast, const float* in, float* out, size_t n);
 /* rand01 (pathTracer.comp:107-110) over n keys (x,y,z) -> 3 floats each. */
 int mc_test_rand01(mc_context* ctx, const uint32_t* xyz, float* out, size_t n);
-/* ds_add/ds_sub/ds_mul/ds_compare (emulateDouble.h.glsl:71-139): op 0..3, n pairs of (hi,lo). */
+/* two-float primitives (emulateDouble.h.glsl): op 0 ds_add, 1 ds_sub, 2 ds_mul, 3 ds_compare, 4 ds_sqrt(a), 5 df64_add,
+ * 6 df64_mult, 7 df64_sqrt(a), 8 ds_twoProd(a.hi,b.hi); n pairs of (hi,lo). */
 int mc_test_ds_op(mc_context* ctx, int op, const float* a, const float* b, float* out, size_t n);
 
 #ifdef __cplusplus

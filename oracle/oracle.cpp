@@ -98,12 +98,14 @@ int oracle_pathtrace(uint32_t W, uint32_t H, uint32_t spp, uint32_t sample_begin
                      uint32_t maxDepth, const float* planes, uint32_t nPlanes, const float* spheres,
                      uint32_t nSpheres, int mathMode, uint32_t row_begin, uint32_t row_end, float* out,
                      int nthreads, uint64_t* counts) {
+    const int precMode = (mathMode >> 8) & 0xff;   // bits 8..15: sphere-test precision branch (0 fp32, 1 fp64, 2 DS, 3 DF64)
+    mathMode &= 0xff;
     if (!W || !H || row_end > H || row_begin > row_end || sample_end > spp || sample_begin > sample_end) return 1;
     if (counts) {
         int nt = nthreads <= 0 ? (int)std::thread::hardware_concurrency() : nthreads;
         if (nt < 1) nt = 1;
         std::vector<OpCounts> per(nt);
-        PT<CountPolicy> pt{planes, nPlanes, spheres, nSpheres, mathMode};
+        PT<CountPolicy> pt{planes, nPlanes, spheres, nSpheres, mathMode, precMode};
         parallel_rows(row_begin, row_end, nt, [&](uint32_t r, int tid) {
             tls_counts() = &per[tid];
             uint32_t gy = H - 1 - r;
@@ -116,7 +118,7 @@ int oracle_pathtrace(uint32_t W, uint32_t H, uint32_t spp, uint32_t sample_begin
                           tot.intersect_calls, tot.bounces, tot.samples};
         for (int i = 0; i < 12; i++) counts[i] = v[i];
     } else {
-        PT<PlainPolicy> pt{planes, nPlanes, spheres, nSpheres, mathMode};
+        PT<PlainPolicy> pt{planes, nPlanes, spheres, nSpheres, mathMode, precMode};
         parallel_rows(row_begin, row_end, nthreads, [&](uint32_t r, int) {
             uint32_t gy = H - 1 - r;
             for (uint32_t gx = 0; gx < W; gx++)
@@ -130,7 +132,7 @@ int oracle_pathtrace(uint32_t W, uint32_t H, uint32_t spp, uint32_t sample_begin
 void oracle_pathtrace_sample(uint32_t gx, uint32_t gy, uint32_t W, uint32_t H, uint32_t samp, uint32_t maxDepth,
                              const float* planes, uint32_t nPlanes, const float* spheres, uint32_t nSpheres,
                              int mathMode, float* rgb) {
-    PT<PlainPolicy> pt{planes, nPlanes, spheres, nSpheres, mathMode};
+    PT<PlainPolicy> pt{planes, nPlanes, spheres, nSpheres, mathMode & 0xff, (mathMode >> 8) & 0xff};
     v3 r = pt.sample(gx, gy, W, H, samp, maxDepth);
     rgb[0] = r.x; rgb[1] = r.y; rgb[2] = r.z;
 }
@@ -142,7 +144,8 @@ void oracle_rand01(uint64_t n, const uint32_t* xyz, float* out) {
         out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
     }
 }
-// op: 0 add, 1 sub, 2 mul, 3 compare (out[2i] = -1/0/1, out[2i+1] = 0)
+// op: 0 ds_add, 1 ds_sub, 2 ds_mul, 3 ds_compare (out[2i] = -1/0/1, out[2i+1] = 0), 4 ds_sqrt(a),
+//     5 df64_add, 6 df64_mult, 7 df64_sqrt(a), 8 ds_twoProd(a.hi, b.hi)
 void oracle_ds_op(int op, uint64_t n, const float* a, const float* b, float* out) {
     for (uint64_t i = 0; i < n; i++) {
         ds2 x{a[2 * i], a[2 * i + 1]}, y{b[2 * i], b[2 * i + 1]}, r{0, 0};
@@ -150,6 +153,11 @@ void oracle_ds_op(int op, uint64_t n, const float* a, const float* b, float* out
             case 0: r = ds_add(x, y); break;
             case 1: r = ds_sub(x, y); break;
             case 2: r = ds_mul(x, y); break;
+            case 4: r = ds_sqrt(x); break;
+            case 5: r = df64_add(x, y); break;
+            case 6: r = df64_mult(x, y); break;
+            case 7: r = df64_sqrt(x); break;
+            case 8: r = ds_twoProd(x.x, y.x); break;
             default: r = ds2{ds_compare(x, y), 0.0f}; break;
         }
         out[2 * i] = r.x; out[2 * i + 1] = r.y;

@@ -265,6 +265,93 @@ inline ds2 ds_mul(ds2 a, ds2 b) {                                          // :1
     return c;
 }
 
+// ---- remaining DS_f32_f32 helpers used by the path tracer's large-sphere branch ------------------------
+// inversesqrt(x) := 1.0f / sqrt(x) (IEEE), the canonical choice of DESIGN.md
+inline float inversesqrt_f32(float x) { return 1.0f / std::sqrt(x); }
+inline ds2 ds_split(float a) {                                             // emulateDouble.h.glsl:181-187 (4097)
+    const float split = 4097.0f;
+    float t = a * split;
+    float a_hi = t - (t - a);
+    float a_lo = a - a_hi;
+    return ds2{a_hi, a_lo};
+}
+inline ds2 ds_twoProd(float a, float b) {                                  // :189-197
+    float p = a * b;
+    ds2 aS = ds_split(a), bS = ds_split(b);
+    float err = ((aS.x * bS.x - p) + aS.x * bS.y + aS.y * bS.x) + aS.y * bS.y;
+    return ds2{p, err};
+}
+inline ds2 ds_sqrt(ds2 a) {                                                // :199-210
+    float xn = inversesqrt_f32(a.x);
+    float yn = a.x * xn;
+    ds2 yn_ds = ds_set(yn);
+    ds2 ynsqr = ds_mul(yn_ds, yn_ds);
+    float diff = ds_sub(a, ynsqr).x;
+    ds2 prod = ds_twoProd(xn, diff);
+    prod.x *= 0.5f; prod.y *= 0.5f;
+    return ds_add(ds_set(yn), prod);
+}
+inline ds2 ds_dot3(ds2 ax, ds2 ay, ds2 az, ds2 bx, ds2 by, ds2 bz) {       // :213-223
+    return ds_add(ds_add(ds_mul(ax, bx), ds_mul(ay, by)), ds_mul(az, bz));
+}
+
+// ---- DF64_F32_F32 package — emulateDouble.h.glsl:225-356 (A. Thall's df64) ---------------------------------
+inline ds2 df64_from_f32(float v) { return ds2{v, 0.0f}; }                 // :232-235
+inline bool df64_lt(ds2 a, ds2 b) { return a.x < b.x || (a.x == b.x && a.y < b.y); }   // :253-255
+inline ds2 quickTwoSum(float a, float b) {                                 // :259-263
+    float s = a + b;
+    float e = b - (s - a);
+    return ds2{s, e};
+}
+inline ds2 twoSum(float a, float b) {                                      // :265-270
+    float s = a + b;
+    float v = s - a;
+    float e = (a - (s - v)) + (b - v);
+    return ds2{s, e};
+}
+inline ds2 df64_add(ds2 a, ds2 b) {                                        // :279-288
+    ds2 s = twoSum(a.x, b.x);
+    ds2 t = twoSum(a.y, b.y);
+    s.y += t.x;
+    s = quickTwoSum(s.x, s.y);
+    s.y += t.y;
+    s = quickTwoSum(s.x, s.y);
+    return s;
+}
+inline ds2 df64_split(float a) {                                           // :292-311 (4097)
+    const float split = 4097.0f;
+    float t = a * split;
+    float a_hi = t - (t - a);
+    float a_lo = a - a_hi;
+    return ds2{a_hi, a_lo};
+}
+inline ds2 df64_twoProd(float a, float b) {                                // :313-321
+    float p = a * b;
+    ds2 aS = df64_split(a), bS = df64_split(b);
+    float err = ((aS.x * bS.x - p) + aS.x * bS.y + aS.y * bS.x) + aS.y * bS.y;
+    return ds2{p, err};
+}
+inline ds2 df64_mult(ds2 a, ds2 b) {                                       // :323-329
+    ds2 p = df64_twoProd(a.x, b.x);
+    p.y += a.x * b.y;
+    p.y += a.y * b.x;
+    p = quickTwoSum(p.x, p.y);
+    return p;
+}
+inline ds2 df64_sqrt(ds2 a) {                                              // :331-342
+    float xn = inversesqrt_f32(a.x);
+    float yn = a.x * xn;
+    ds2 yn_df = df64_from_f32(yn);
+    ds2 ynsqr = df64_mult(yn_df, yn_df);
+    float diff = df64_add(a, df64_mult(ynsqr, df64_from_f32(-1.0f))).x;
+    ds2 prod = df64_twoProd(xn, diff);
+    prod.x *= 0.5f; prod.y *= 0.5f;
+    return df64_add(df64_from_f32(yn), prod);
+}
+inline ds2 df64_dot3(ds2 ax, ds2 ay, ds2 az, ds2 bx, ds2 by, ds2 bz) {     // :346-356
+    return df64_add(df64_add(df64_mult(ax, bx), df64_mult(ay, by)), df64_mult(az, bz));
+}
+
 // Two-float Mandelbrot: the composition SURVEY.md §8a row M3 / DESIGN.md defines (the reference has
 // no df64 Mandelbrot; only these primitives).  Same loop structure as mandelbrot.comp:40-46.
 inline uint32_t mandel_ds_pixel(uint32_t gx, uint32_t gy, uint32_t W, uint32_t H, uint32_t maxIter,
@@ -369,6 +456,66 @@ struct PT {
     const float* planes; uint32_t nPlanes;     // 12 floats each: equation.xyzw | e.xyzw | c.xyzw   (pathTracer.comp:59)
     const float* spheres; uint32_t nSpheres;   // 12 floats each: geo.xyzw      | e.xyzw | c.xyzw   (pathTracer.comp:60)
     int mathMode;
+    // Which `#if` branch of the sphere test is compiled in (emulateDouble.h.glsl:13-26; all FALSE in the
+    // reference's default build): 0 fp32 only, 1 USE_NATIVE_FP64, 2 DS_f32_f32, 3 DF64_F32_F32.
+    int precMode = 0;
+
+    // pathTracer.comp:134-137 / :146-149 / :216-219: does this sphere need the extended-precision test?
+    static inline bool needs_precision(const float* sp, v3 o) {
+        const float maxLen = 500.0f;
+        v3 c{sp[0], sp[1], sp[2]};
+        v3 co{c.x - o.x, c.y - o.y, c.z - o.z};
+        auto d3 = [](v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; };
+        return sp[3] > maxLen || d3(c, c) > maxLen * maxLen || d3(o, o) > maxLen * maxLen || d3(co, co) > maxLen * maxLen;
+    }
+    // Extended-precision sphere distance (the value assigned to `d`); returns false for `continue` (det < 0).
+    bool sphere_extended(const float* sp, const Ray& ray, float& d) const {
+        const float eps = 1e-4f, inf = 1e20f;
+        if (precMode == 1) {                                               // :139-142 native fp64
+            double ocx = (double)sp[0] - (double)ray.o.x, ocy = (double)sp[1] - (double)ray.o.y, ocz = (double)sp[2] - (double)ray.o.z;
+            double dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
+            double b = (ocx * dx + ocy * dy) + ocz * dz;
+            double det = (b * b - ((ocx * ocx + ocy * ocy) + ocz * ocz)) + (double)(sp[3] * sp[3]);
+            if (det < 0) return false;
+            det = std::sqrt(det);
+            d = (float)(b - det);
+            if (!(d > eps)) { d = (float)(b + det); if (!(d > eps)) d = inf; }
+            return true;
+        }
+        if (precMode == 2) {                                               // :151-204 DS_f32_f32
+            ds2 ocX = ds_add(ds_set(sp[0]), ds_set(-ray.o.x)), ocY = ds_add(ds_set(sp[1]), ds_set(-ray.o.y)),
+                ocZ = ds_add(ds_set(sp[2]), ds_set(-ray.o.z));
+            ds2 rdX = ds_set(ray.d.x), rdY = ds_set(ray.d.y), rdZ = ds_set(ray.d.z);
+            ds2 b = ds_dot3(ocX, ocY, ocZ, rdX, rdY, rdZ);
+            ds2 w = ds_set(sp[3]);
+            ds2 det = ds_add(ds_sub(ds_mul(b, b), ds_dot3(ocX, ocY, ocZ, ocX, ocY, ocZ)), ds_mul(w, w));
+            if (ds_compare(det, ds_set(0.0f)) < 0.0f) return false;
+            det = ds_sqrt(det);
+            ds2 eps_ds = ds_set(eps);
+            ds2 bMinus = ds_sub(b, det), bPlus = ds_add(b, det);
+            ds2 d_ds = bMinus; d = d_ds.x;
+            if (ds_compare(d_ds, eps_ds) <= 0.0f) {
+                d_ds = bPlus; d = d_ds.x;
+                if (ds_compare(d_ds, eps_ds) <= 0.0f) d = inf;
+            }
+            return true;
+        }
+        // :221-255 DF64_F32_F32
+        ds2 ocX = df64_add(df64_from_f32(sp[0]), df64_from_f32(-ray.o.x)), ocY = df64_add(df64_from_f32(sp[1]), df64_from_f32(-ray.o.y)),
+            ocZ = df64_add(df64_from_f32(sp[2]), df64_from_f32(-ray.o.z));
+        ds2 rdX = df64_from_f32(ray.d.x), rdY = df64_from_f32(ray.d.y), rdZ = df64_from_f32(ray.d.z);
+        ds2 b = df64_dot3(ocX, ocY, ocZ, rdX, rdY, rdZ);
+        ds2 w = df64_from_f32(sp[3]);
+        ds2 det = df64_add(df64_add(df64_mult(b, b), df64_mult(df64_dot3(ocX, ocY, ocZ, ocX, ocY, ocZ), df64_from_f32(-1.0f))),
+                           df64_mult(w, w));
+        if (df64_lt(det, df64_from_f32(0.0f))) return false;
+        det = df64_sqrt(det);
+        float bMinus = df64_add(b, df64_mult(det, df64_from_f32(-1.0f))).x;
+        float bPlus = df64_add(b, det).x;
+        d = bMinus;
+        if (!(d > eps)) { d = bPlus; if (!(d > eps)) d = inf; }
+        return true;
+    }
 
     // intersect — pathTracer.comp:112-131 + :316-341 (fp32 branch; all #if variants compiled out by
     // emulateDouble.h.glsl:13-26)
@@ -390,6 +537,12 @@ struct PT {
         }
         for (uint32_t i = 0; i < nSpheres; i++) {                          // :127
             const float* sp = spheres + 12 * i;
+            if (precMode != 0 && needs_precision(sp, ray.o)) {             // :132-315 (compiled out by default)
+                if (!sphere_extended(sp, ray, d)) continue;
+                P::c_cmp();
+                if (d < t) { t = d; hit.objType = eSphere; hit.objIdx = (int)i; }   // :333
+                continue;
+            }
             v3 oc = sub(v3{sp[0], sp[1], sp[2]}, ray.o);                   // :317
             float b = dot(oc, ray.d);                                      // :318
             float det = P::add(P::sub(P::mul(b, b), dot(oc, oc)), P::mul(sp[3], sp[3]));

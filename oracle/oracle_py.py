@@ -34,6 +34,22 @@ REF_VIEW = np.array([-0.445, 0.0, 0.0, 0.0, 2.34, 0.0, 2.34, 0.0], dtype=np.floa
 REF_KCOLOR = np.array([0.1, 0.7, 0.6, 0.0], dtype=np.float32)
 
 MATH_LIBM, MATH_MC = 0, 1
+PREC_F32, PREC_FP64, PREC_DS, PREC_DF64 = 0, 1, 2, 3   # sphere-test branch (emulateDouble.h.glsl:13-26)
+
+# Scene of TEST_PRECISION_WITH_LARGE_SPHERE_WALLS != 0 (src/pathtracerApp.h:22-23,28-38): one dummy plane, six
+# radius-1e5 wall spheres (the classic smallpt walls), then the mirror / glass / light spheres.  DATA.
+LARGE_SPHERE_PLANES = np.array([1, 0, 0, 1000, 0, 0, 0, 0, 1, 1, 1, 1], dtype=np.float64).astype(np.float32)
+LARGE_SPHERE_SPHERES = np.array([
+    1e5 - 2.6, 0, 0, 1e5, 0, 0, 0, 0, .85, .25, .25, 1,     # Left
+    1e5 + 2.6, 0, 0, 1e5, 0, 0, 0, 0, .25, .35, .85, 1,     # Right
+    0, 1e5 + 2, 0, 1e5, 0, 0, 0, 0, .75, .75, .75, 1,       # Top
+    0, -1e5 - 2, 0, 1e5, 0, 0, 0, 0, .75, .75, .75, 1,      # Bottom
+    0, 0, -1e5 - 2.8, 1e5, 0, 0, 0, 0, .85, .85, .25, 1,    # Back
+    0, 0, 1e5 + 7.9, 1e5, 0, 0, 0, 0, 0.1, 0.7, 0.7, 1,     # Front
+    -1.3, -1.2, -1.3, 0.8, 0, 0, 0, 0, .999, .999, .999, 2,
+    1.3, -1.2, -0.2, 0.8, 0, 0, 0, 0, .999, .999, .999, 3,
+    0, 2 * 0.8, 0, 0.2, 100, 100, 100, 0, 0, 0, 0, 1,
+], dtype=np.float64).astype(np.float32)
 
 _u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
@@ -123,7 +139,9 @@ def rotate180(rgba8, W, H):
 
 
 def pathtrace(W, H, spp, planes=DEFAULT_PLANES, spheres=DEFAULT_SPHERES, math_mode=MATH_LIBM, max_depth=12,
-              sample_begin=0, sample_end=None, row_begin=0, row_end=None, acc=None, nthreads=0, counts=False):
+              sample_begin=0, sample_end=None, row_begin=0, row_end=None, acc=None, nthreads=0, counts=False,
+              precision=PREC_F32):
+    math_mode = math_mode | (precision << 8)
     sample_end = spp if sample_end is None else sample_end
     row_end = H if row_end is None else row_end
     out = np.zeros((row_end - row_begin, W, 4), np.float32) if acc is None else np.ascontiguousarray(acc, np.float32).copy()
@@ -158,12 +176,15 @@ def rand01(xyz):
     return out
 
 
+DS_OPS = {"add": 0, "sub": 1, "mul": 2, "compare": 3, "sqrt": 4, "df64_add": 5, "df64_mult": 6, "df64_sqrt": 7,
+          "twoprod": 8}
+
+
 def ds_op(op, a, b):
     a = np.ascontiguousarray(a, np.float32).reshape(-1, 2)
     b = np.ascontiguousarray(b, np.float32).reshape(-1, 2)
     out = np.empty(a.shape, np.float32)
-    lib().oracle_ds_op({"add": 0, "sub": 1, "mul": 2, "compare": 3}[op], a.shape[0], a.reshape(-1), b.reshape(-1),
-                       out.reshape(-1))
+    lib().oracle_ds_op(DS_OPS[op], a.shape[0], a.reshape(-1), b.reshape(-1), out.reshape(-1))
     return out
 
 

@@ -394,3 +394,46 @@ def test_k2_render_reproduces_the_reference_image_per_pixel(ctx, B):
         rmse = float(np.sqrt((d.astype(np.float64) ** 2).mean()))
         print(f"mode {mode}: exact {exact:.4f} within1 {within1:.4f} rmse {rmse:.3f} max {d.max()}")
         assert exact > 0.92 and within1 > 0.985 and rmse < 0.8
+
+
+# ---------------------------------------------------------------------------------------------------
+# the reference's actual use of emulated double — extended-precision sphere tests
+# (pathTracer.comp:132-256) with the TEST_PRECISION_WITH_LARGE_SPHERE_WALLS scene (pathtracerApp.h:28-38)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("op", ["sqrt", "df64_add", "df64_mult", "df64_sqrt", "twoprod"])
+def test_df64_and_ds_sqrt_primitives_bit_exact(ctx, O, op):
+    rng = np.random.default_rng(11)
+    n = 20000
+    hi = (rng.uniform(0.01, 1.0, n) * 10.0 ** rng.integers(-3, 10, n)).astype(np.float32)
+    lo = (hi * rng.uniform(-1, 1, n) * 2.0 ** -24).astype(np.float32)
+    hi2 = (rng.standard_normal(n) * 10.0 ** rng.integers(-3, 6, n)).astype(np.float32)
+    lo2 = (hi2 * rng.uniform(-1, 1, n) * 2.0 ** -24).astype(np.float32)
+    a, b = np.stack([hi, lo], 1), np.stack([hi2, lo2], 1)
+    assert np.array_equal(bits(ctx.test_ds_op(op, a, b)), bits(O.ds_op(op, a, b)))
+
+
+@pytest.mark.parametrize("prec", [1, 2, 3])
+def test_pathtrace_large_sphere_scene_precision_branches(ctx, B, O, prec):
+    """Strict math: bit-identical to the oracle for each precision branch, S = 1 and S = 16."""
+    W, H, spp = 40, 28, 17
+    ref = O.pathtrace(W, H, spp, planes=O.LARGE_SPHERE_PLANES, spheres=O.LARGE_SPHERE_SPHERES, math_mode=O.MATH_MC, precision=prec)
+    for S in (1, 16):
+        p = B.pathtrace_params(W, H, spp, flags=B.pt_precision(prec) | B.pt_force_s(S))
+        out = ctx.pathtrace(p, planes=O.LARGE_SPHERE_PLANES, spheres=O.LARGE_SPHERE_SPHERES)
+        assert np.array_equal(bits(out), bits(ref)), (prec, S)
+
+
+def test_large_sphere_precision_experiment(ctx, B, O):
+    """The reference's experiment (pathtracerApp.h:11): radius-1e5 wall spheres break the fp32 sphere test (image far
+    too dark), every extended-precision branch restores the image of the plane-walled default scene."""
+    W, H, spp = 120, 80, 64
+    planes, spheres = O.LARGE_SPHERE_PLANES, O.LARGE_SPHERE_SPHERES
+    mean = {}
+    for prec in (0, 1, 2, 3):
+        p = B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, flags=B.pt_precision(prec))
+        mean[prec] = float(ctx.pathtrace(p, planes=planes, spheres=spheres)[..., :3].mean())
+    default = float(ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST))[..., :3].mean())
+    print("mean radiance: fp32 %.2f  fp64 %.2f  ds %.2f  df64 %.2f  | plane-walled scene %.2f" % (mean[0], mean[1], mean[2], mean[3], default))
+    assert mean[0] < default - 10.0                      # fp32 with 1e5-radius spheres: broken
+    for prec in (1, 2, 3):
+        assert abs(mean[prec] - default) < 1.5           # extended precision: matches the plane scene

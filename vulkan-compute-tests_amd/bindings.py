@@ -19,6 +19,12 @@ PRECISION_F32, PRECISION_DS = 0, 1
 PT_MATH_STRICT, PT_MATH_FAST = 0, 1
 MANDEL_FMA = 1
 PT_GENERIC_KERNEL = 1
+PT_PREC_F32, PT_PREC_FP64, PT_PREC_DS, PT_PREC_DF64 = 0, 1, 2, 3
+DS_OPS = {"add": 0, "sub": 1, "mul": 2, "compare": 3, "sqrt": 4, "df64_add": 5, "df64_mult": 6, "df64_sqrt": 7, "twoprod": 8}
+
+
+def pt_precision(x):
+    return int(x) << 16
 
 
 def pt_force_s(s):
@@ -262,7 +268,7 @@ class Context:
         a = np.ascontiguousarray(a, np.float32).reshape(-1, 2)
         b = np.ascontiguousarray(b, np.float32).reshape(-1, 2)
         out = np.empty(a.shape, np.float32)
-        _check(lib().mc_test_ds_op(self._h, {"add": 0, "sub": 1, "mul": 2, "compare": 3}[op], _ptr(a), _ptr(b), _ptr(out),
+        _check(lib().mc_test_ds_op(self._h, DS_OPS[op], _ptr(a), _ptr(b), _ptr(out),
                                    a.shape[0]), "mc_test_ds_op")
         return out
 

@@ -95,10 +95,16 @@ __global__ void test_ds_kernel(int op, const float* __restrict__ a, const float*
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     ds2 x{a[2 * i], a[2 * i + 1]}, y{b[2 * i], b[2 * i + 1]}, r{0.0f, 0.0f};
+    auto rsq = [](float v) { return dm::inversesqrt<false>(v); };
     switch (op) {
         case 0: r = ds_add(x, y); break;
         case 1: r = ds_sub(x, y); break;
         case 2: r = ds_mul(x, y); break;
+        case 4: r = ds_sqrt(x, rsq); break;
+        case 5: r = df64_add(x, y); break;
+        case 6: r = df64_mult(x, y); break;
+        case 7: r = df64_sqrt(x, rsq); break;
+        case 8: r = ds_twoProd(x.hi, y.hi); break;
         default: r = ds2{ds_compare(x, y), 0.0f}; break;
     }
     out[2 * i] = r.hi; out[2 * i + 1] = r.lo;

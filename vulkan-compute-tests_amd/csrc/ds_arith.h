@@ -81,4 +81,85 @@ __device__ __forceinline__ ds2 ds_mul(ds2 a, ds2 b) {                      // :1
 // ds_mul(a, a): same operation sequence with b == a (the compiler CSEs the duplicated split).
 __device__ __forceinline__ ds2 ds_sqr(ds2 a) { return ds_mul(a, a); }
 
+// ---- helpers of the path tracer's large-sphere branch (pathTracer.comp:144-213) ---------------------------
+// `RSQ` supplies inversesqrt: IEEE 1/sqrt in strict builds, v_rsq_f32 in fast builds.
+__device__ __forceinline__ ds2 ds_split(float a) {                         // emulateDouble.h.glsl:181-187 (4097)
+    const float split = 4097.0f;
+    float t = a * split;
+    float a_hi = t - (t - a);
+    float a_lo = a - a_hi;
+    return ds2{a_hi, a_lo};
+}
+__device__ __forceinline__ ds2 ds_twoProd(float a, float b) {              // :189-197
+    float p = a * b;
+    ds2 aS = ds_split(a), bS = ds_split(b);
+    float err = ((aS.hi * bS.hi - p) + aS.hi * bS.lo + aS.lo * bS.hi) + aS.lo * bS.lo;
+    return ds2{p, err};
+}
+template <class RSQ>
+__device__ __forceinline__ ds2 ds_sqrt(ds2 a, RSQ rsq) {                   // :199-210
+    float xn = rsq(a.hi);
+    float yn = a.hi * xn;
+    ds2 yn_ds = ds_set(yn);
+    ds2 ynsqr = ds_mul(yn_ds, yn_ds);
+    float diff = ds_sub(a, ynsqr).hi;
+    ds2 prod = ds_twoProd(xn, diff);
+    prod.hi *= 0.5f; prod.lo *= 0.5f;
+    return ds_add(ds_set(yn), prod);
+}
+__device__ __forceinline__ ds2 ds_dot3(ds2 ax, ds2 ay, ds2 az, ds2 bx, ds2 by, ds2 bz) {   // :213-223
+    return ds_add(ds_add(ds_mul(ax, bx), ds_mul(ay, by)), ds_mul(az, bz));
+}
+
+// ---- DF64_F32_F32 package — emulateDouble.h.glsl:225-356 (pathTracer.comp:214-256) --------------------------
+__device__ __forceinline__ ds2 df64_from_f32(float v) { return ds2{v, 0.0f}; }                     // :232-235
+__device__ __forceinline__ bool df64_lt(ds2 a, ds2 b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }   // :253-255
+__device__ __forceinline__ ds2 quickTwoSum(float a, float b) {             // :259-263
+    float s = a + b;
+    float e = b - (s - a);
+    return ds2{s, e};
+}
+__device__ __forceinline__ ds2 twoSum(float a, float b) {                  // :265-270
+    float s = a + b;
+    float v = s - a;
+    float e = (a - (s - v)) + (b - v);
+    return ds2{s, e};
+}
+__device__ __forceinline__ ds2 df64_add(ds2 a, ds2 b) {                    // :279-288
+    ds2 s = twoSum(a.hi, b.hi);
+    ds2 t = twoSum(a.lo, b.lo);
+    s.lo += t.hi;
+    s = quickTwoSum(s.hi, s.lo);
+    s.lo += t.lo;
+    s = quickTwoSum(s.hi, s.lo);
+    return s;
+}
+__device__ __forceinline__ ds2 df64_twoProd(float a, float b) {            // :313-321 (split 4097, :292-311)
+    float p = a * b;
+    ds2 aS = ds_split(a), bS = ds_split(b);
+    float err = ((aS.hi * bS.hi - p) + aS.hi * bS.lo + aS.lo * bS.hi) + aS.lo * bS.lo;
+    return ds2{p, err};
+}
+__device__ __forceinline__ ds2 df64_mult(ds2 a, ds2 b) {                   // :323-329
+    ds2 p = df64_twoProd(a.hi, b.hi);
+    p.lo += a.hi * b.lo;
+    p.lo += a.lo * b.hi;
+    p = quickTwoSum(p.hi, p.lo);
+    return p;
+}
+template <class RSQ>
+__device__ __forceinline__ ds2 df64_sqrt(ds2 a, RSQ rsq) {                 // :331-342
+    float xn = rsq(a.hi);
+    float yn = a.hi * xn;
+    ds2 yn_df = df64_from_f32(yn);
+    ds2 ynsqr = df64_mult(yn_df, yn_df);
+    float diff = df64_add(a, df64_mult(ynsqr, df64_from_f32(-1.0f))).hi;
+    ds2 prod = df64_twoProd(xn, diff);
+    prod.hi *= 0.5f; prod.lo *= 0.5f;
+    return df64_add(df64_from_f32(yn), prod);
+}
+__device__ __forceinline__ ds2 df64_dot3(ds2 ax, ds2 ay, ds2 az, ds2 bx, ds2 by, ds2 bz) {   // :346-356
+    return df64_add(df64_add(df64_mult(ax, bx), df64_mult(ay, by)), df64_mult(az, bz));
+}
+
 }  // namespace mc

@@ -10,7 +10,10 @@
 //    is straight-line VALU for U iterations and all bookkeeping (OR of the U ballots, "every lane
 //    done" early-out, iteration counter) runs on the scalar unit.  Per-lane iteration counts are
 //    reconstructed from the saved ballots only in the (rare) blocks where some lane escapes.
-//    Interior tiles therefore issue 8 fp32 ops + 1 compare per pixel-iteration.
+//  * v_cmp_*_f32 costs 4 issue cycles on gfx950 but v_or_b32 only 2 (tools/valu_microbench.hip): the fp32
+//    fast path ORs the bit patterns of the block's |z|^2 values (bit 30 set <=> value >= 2) and compares
+//    once per block; the exact ballots are recomputed from the block's saved state only when an unfinished
+//    lane may have escaped.  Interior tiles issue 8 fp32 ops + 1 v_or per pixel-iteration (18 cycles).
 //  * unfused IEEE fp32 in GLSL source order: this TU is built with -ffp-contract=off.
 //    zx*zx and zy*zy are computed once per iteration and reused by the magnitude test and the next
 //    update — identical values, so identical results to the literal `dot(z,z)` (mandelbrot.comp:43-44).
@@ -47,7 +50,8 @@ struct StateF32 {
         cy = a.cy_hi + (y - 0.5f) * a.sy_hi;
         zx = zy = sx = sy = 0.0f;
     }
-    __device__ __forceinline__ bool step() {       // :43-44
+    // One iteration (:43), returns |z|^2 = dot(z,z) of the new z (:44).
+    __device__ __forceinline__ float advance() {
         float nzx, nzy;
         if (FMA) {   // NON-PARITY diagnostic variant (MC_MANDEL_FMA)
             nzx = __builtin_fmaf(zx, zx, -sy) + cx;
@@ -58,8 +62,16 @@ struct StateF32 {
         }
         zx = nzx; zy = nzy;
         sx = zx * zx; sy = zy * zy;
-        return (sx + sy) > 2.0f;
+        return sx + sy;
     }
+    __device__ __forceinline__ bool step() { return advance() > 2.0f; }   // :44
+    // Conservative escape filter on the bit pattern of |z|^2 (>= 0, or NaN after an overflow): every value
+    // > 2.0f has bit 30 set or is 0x40000001..., every value < 2.0f has bit 30 clear, so the bitwise OR of a
+    // block's magnitudes exceeds 0x40000000 whenever any of them exceeded 2.0f (no false negatives; the only
+    // false positives involve a magnitude of exactly 2.0f).  v_or_b32 issues in 2 cycles, v_cmp_*_f32 in 4.
+    static constexpr bool kHasBitFilter = true;
+    __device__ __forceinline__ uint32_t advance_bits() { return __float_as_uint(advance()); }
+    static __device__ __forceinline__ bool bits_may_have_escaped(uint32_t or_of_bits) { return or_of_bits > 0x40000000u; }
 };
 
 struct StateDS {
@@ -71,6 +83,9 @@ struct StateDS {
         cy = ds_add(ds2{a.cy_hi, a.cy_lo}, ds_mul(ds_set(y - 0.5f), ds2{a.sy_hi, a.sy_lo}));
         zx = zy = sx = sy = ds_set(0.0f);
     }
+    static constexpr bool kHasBitFilter = false;   // 142 flops per iteration: the exact compare is noise
+    __device__ __forceinline__ uint32_t advance_bits() { return 0u; }
+    static __device__ __forceinline__ bool bits_may_have_escaped(uint32_t) { return true; }
     __device__ __forceinline__ bool step() {
         ds2 zxy = ds_mul(zx, zy);
         ds2 twoxy = ds2{2.0f * zxy.hi, 2.0f * zxy.lo};   // exact
@@ -92,6 +107,18 @@ __device__ __forceinline__ uint32_t escape_time(State& st, uint32_t max_iter, bo
     uint32_t n = max_iter;
     uint32_t i = 0;
     for (; i + U <= max_iter; i += U) {
+        if (State::kHasBitFilter) {
+            // fast path: U iterations of pure add/mul/or, ONE compare per block; the exact per-iteration
+            // ballots below are evaluated (from the saved state) only if some unfinished lane may have escaped
+            State probe = st;
+            uint32_t acc = 0u;
+#pragma unroll
+            for (int k = 0; k < U; k++) acc |= probe.advance_bits();
+            if ((__ballot(State::bits_may_have_escaped(acc)) & ~done) == 0ull) {
+                st = probe;
+                continue;
+            }
+        }
         uint64_t b[U];
         uint64_t any = 0;
 #pragma unroll

@@ -91,13 +91,16 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
         v3 e{sp[4], sp[5], sp[6]};
         if (h_dot(e, e) > 0.0f) a.scene.emissive_mask |= 1u << i;
     }
-    const bool slab = analyse_slabs(planes, n_planes, n_spheres, a.scene) && !(p->flags & MC_PT_GENERIC_KERNEL);
+    const int prec = (int)((p->flags >> 16) & 0xfu);   // MC_PT_PRECISION(x)
+    if (prec > 3) return MC_ERR_INVALID_ARGUMENT;
+    const bool slab = prec == 0 && analyse_slabs(planes, n_planes, n_spheres, a.scene) && !(p->flags & MC_PT_GENERIC_KERNEL);
     const uint32_t rows = tile_rows(p->row_begin, p->row_end, a.row_block, a.row_stride);
     int S = (int)((p->flags >> 8) & 0xffu);   // MC_PT_FORCE_S(s)
     if (S == 0) S = choose_S((uint64_t)rows * p->width, p->sample_end - p->sample_begin);
     if (S != 1 && S != 4 && S != 16) return MC_ERR_INVALID_ARGUMENT;
-    int rc = p->math_mode == MC_PT_MATH_FAST ? pt::launch_fast(a, slab ? 1 : 0, S, rows, s)
-                                             : pt::launch_strict(a, slab ? 1 : 0, S, rows, s);
+    if (prec != 0 && S == 4) S = (p->sample_end - p->sample_begin) >= 16 ? 16 : 1;   // precision variants exist for S = 1, 16
+    int rc = p->math_mode == MC_PT_MATH_FAST ? pt::launch_fast(a, slab ? 1 : 0, S, prec, rows, s)
+                                             : pt::launch_strict(a, slab ? 1 : 0, S, prec, rows, s);
     if (rc) return rc;
     MC_HIP_TRY(hipGetLastError());
     return MC_OK;

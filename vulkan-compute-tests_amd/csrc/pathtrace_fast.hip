@@ -4,8 +4,8 @@
 
 namespace mc {
 namespace pt {
-int launch_fast(const PTArgs& a, int variant, int S, uint32_t tile_rows, hipStream_t s) {
-    return launch_impl<true>(a, variant, S, tile_rows, s);
+int launch_fast(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s) {
+    return launch_impl<true>(a, variant, S, prec, tile_rows, s);
 }
 }  // namespace pt
 }  // namespace mc

@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mc_internal.h"
+#include "ds_arith.h"
 #include "mc_math.h"
 
 namespace mc {
@@ -101,9 +102,68 @@ __device__ __forceinline__ v3 rand01(uint32_t x, uint32_t y, uint32_t z) {
 constexpr float kEps = 1e-4f, kTriEps = 1e-7f, kInf = 1e20f;   // pathTracer.comp:103-105
 constexpr float kPi = 3.141592653589793f;                       // :102
 
+// ---- extended-precision sphere test (pathTracer.comp:132-256; every variant is compiled OUT in the reference's
+// default build, emulateDouble.h.glsl:13-26).  Prec: 1 = USE_NATIVE_FP64 (:139-142), 2 = DS_f32_f32 (:151-204),
+// 3 = DF64_F32_F32 (:221-255).  Used with the TEST_PRECISION_WITH_LARGE_SPHERE_WALLS scene (pathtracerApp.h:28-35).
+__device__ __forceinline__ bool needs_precision(const float* sp, v3 o) {     // :134-137 / :146-149 / :216-219
+    const float maxLen = 500.0f;
+    v3 c{sp[0], sp[1], sp[2]};
+    v3 co = c - o;
+    return sp[3] > maxLen || dot(c, c) > maxLen * maxLen || dot(o, o) > maxLen * maxLen || dot(co, co) > maxLen * maxLen;
+}
+// Returns false for the shader's `continue` (det < 0); otherwise dd = the value the shader assigns to `d`.
+template <bool Fast, int Prec>
+__device__ __forceinline__ bool sphere_extended(const float* sp, float r2, v3 o, v3 d, float& dd) {
+    auto rsq = [](float x) { return dm::inversesqrt<Fast>(x); };
+    if (Prec == 1) {
+        double ocx = (double)sp[0] - (double)o.x, ocy = (double)sp[1] - (double)o.y, ocz = (double)sp[2] - (double)o.z;
+        double dx = d.x, dy = d.y, dz = d.z;
+        double b = (ocx * dx + ocy * dy) + ocz * dz;
+        double det = (b * b - ((ocx * ocx + ocy * ocy) + ocz * ocz)) + (double)r2;   // geo.w*geo.w is an fp32 product (:140)
+        if (det < 0) return false;
+        det = __builtin_sqrt(det);
+        dd = (float)(b - det);
+        if (!(dd > kEps)) { dd = (float)(b + det); if (!(dd > kEps)) dd = kInf; }
+        return true;
+    } else if (Prec == 2) {
+        ds2 ocX = ds_add(ds_set(sp[0]), ds_set(-o.x)), ocY = ds_add(ds_set(sp[1]), ds_set(-o.y)), ocZ = ds_add(ds_set(sp[2]), ds_set(-o.z));
+        ds2 rdX = ds_set(d.x), rdY = ds_set(d.y), rdZ = ds_set(d.z);
+        ds2 b = ds_dot3(ocX, ocY, ocZ, rdX, rdY, rdZ);
+        ds2 w = ds_set(sp[3]);
+        ds2 det = ds_add(ds_sub(ds_mul(b, b), ds_dot3(ocX, ocY, ocZ, ocX, ocY, ocZ)), ds_mul(w, w));
+        if (ds_compare(det, ds_set(0.0f)) < 0.0f) return false;
+        det = ds_sqrt(det, rsq);
+        ds2 eps_ds = ds_set(kEps);
+        ds2 bMinus = ds_sub(b, det), bPlus = ds_add(b, det);
+        ds2 d_ds = bMinus;
+        dd = d_ds.hi;
+        if (ds_compare(d_ds, eps_ds) <= 0.0f) {
+            d_ds = bPlus;
+            dd = d_ds.hi;
+            if (ds_compare(d_ds, eps_ds) <= 0.0f) dd = kInf;
+        }
+        return true;
+    } else {
+        ds2 ocX = df64_add(df64_from_f32(sp[0]), df64_from_f32(-o.x)), ocY = df64_add(df64_from_f32(sp[1]), df64_from_f32(-o.y)),
+            ocZ = df64_add(df64_from_f32(sp[2]), df64_from_f32(-o.z));
+        ds2 rdX = df64_from_f32(d.x), rdY = df64_from_f32(d.y), rdZ = df64_from_f32(d.z);
+        ds2 b = df64_dot3(ocX, ocY, ocZ, rdX, rdY, rdZ);
+        ds2 w = df64_from_f32(sp[3]);
+        ds2 det = df64_add(df64_add(df64_mult(b, b), df64_mult(df64_dot3(ocX, ocY, ocZ, ocX, ocY, ocZ), df64_from_f32(-1.0f))),
+                           df64_mult(w, w));
+        if (df64_lt(det, df64_from_f32(0.0f))) return false;
+        det = df64_sqrt(det, rsq);
+        float bMinus = df64_add(b, df64_mult(det, df64_from_f32(-1.0f))).hi;
+        float bPlus = df64_add(b, det).hi;
+        dd = bMinus;
+        if (!(dd > kEps)) { dd = bPlus; if (!(dd > kEps)) dd = kInf; }
+        return true;
+    }
+}
+
 // intersect — pathTracer.comp:112-131 + :316-341.  Returns the hit object id (planes 0..NP-1, spheres
 // NP..NP+NS-1) or -1, and the ray parameter.  NP/NS < 0 select run-time counts.
-template <bool Fast, int NP, int NS, bool Slab>
+template <bool Fast, int NP, int NS, bool Slab, int Prec>
 __device__ __forceinline__ int intersect(const SceneArgs& sc, v3 o, v3 d, float& t_out) {
     const int np = NP >= 0 ? NP : (int)sc.n_planes;
     const int ns = NS >= 0 ? NS : (int)sc.n_spheres;
@@ -141,10 +201,18 @@ __device__ __forceinline__ int intersect(const SceneArgs& sc, v3 o, v3 d, float&
 #pragma unroll
     for (int i = 0; i < ns; i++) {
         const float* sp = sc.obj + 12 * (np + i);
+        bool extended = false;
+        if (Prec != 0) {
+            extended = needs_precision(sp, o);
+            if (extended) {
+                float dd;
+                if (sphere_extended<Fast, Prec>(sp, sc.r2[i], o, d, dd) && dd < t) { t = dd; id = np + i; }   // :333
+            }
+        }
         v3 oc = v3{sp[0], sp[1], sp[2]} - o;                                 // :317
         float b = dot(oc, d);                                                // :318
         float det = (b * b - dot(oc, oc)) + sc.r2[i];
-        if (!(det < 0.0f)) {                                                 // :319
+        if (!extended && !(det < 0.0f)) {                                    // :319
             float sq = dm::fsqrt<Fast>(det);
             float dd = b - sq;                                               // :322,324
             if (dd <= kEps) {                                                // :325
@@ -159,7 +227,7 @@ __device__ __forceinline__ int intersect(const SceneArgs& sc, v3 o, v3 d, float&
 }
 
 // One sample: returns accrad (pathTracer.comp:356-449).
-template <bool Fast, int NP, int NS, bool Slab>
+template <bool Fast, int NP, int NS, bool Slab, int Prec>
 __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restrict__ lds_obj, uint32_t gx, uint32_t gy,
                                            uint32_t samp) {
     const SceneArgs& sc = a.scene;
@@ -180,7 +248,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
 
     for (uint32_t depth = 0; depth < a.max_depth; depth++) {              // :367
         float t;
-        int id = intersect<Fast, NP, NS, Slab>(sc, ro, rd, t);
+        int id = intersect<Fast, NP, NS, Slab, Prec>(sc, ro, rd, t);
         if (id < 0) break;   // :369 `continue` with an unchanged ray misses again at every later depth: no effect
         v3 x = ro + rd * t;                                               // :374 (o + t*d: fp32 mul is commutative)
         const float* obj = lds_obj + 12 * id;                             // per-lane fetch from LDS
@@ -216,7 +284,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 dm::sincos_angle<Fast>(phi, rnd.y, sphi, cphi);
                 v3 l = normalize<Fast>(((su * cphi) * sin_a + (sv * sphi) * sin_a) + sw * cos_a);   // :413
                 float tne;
-                int idne = intersect<Fast, NP, NS, Slab>(sc, x, l, tne);  // :420 shadow ray
+                int idne = intersect<Fast, NP, NS, Slab, Prec>(sc, x, l, tne);  // :420 shadow ray
                 if (idne == np + i) {
                     float omega = (2.0f * kPi) * (1.0f - cos_a_max);      // :421
                     accrad = accrad + ((divs<Fast>(accmat, kPi) * dm::gmax(dot(l, nl), 0.0f)) * le) * omega;   // :422
@@ -276,7 +344,7 @@ template <> struct WaveTile<64> { static constexpr uint32_t w = 1, h = 1; };
 template <int S> constexpr uint32_t block_w() { return 2u * WaveTile<S>::w; }
 template <int S> constexpr uint32_t block_h() { return 2u * WaveTile<S>::h; }
 
-template <bool Fast, int NP, int NS, bool Slab, int S>
+template <bool Fast, int NP, int NS, bool Slab, int S, int Prec>
 __global__ void __launch_bounds__(256) pathtrace_kernel(PTArgs a) {
     __shared__ float lds_obj[(kMaxPlanes + kMaxSpheres) * 12];
     {
@@ -302,7 +370,7 @@ __global__ void __launch_bounds__(256) pathtrace_kernel(PTArgs a) {
         const uint32_t s = base + j;
         v3 q{0.0f, 0.0f, 0.0f};
         if (valid && s < a.sample_end) {
-            v3 rad = trace_sample<Fast, NP, NS, Slab>(a, lds_obj, gx, gy, s);
+            v3 rad = trace_sample<Fast, NP, NS, Slab, Prec>(a, lds_obj, gx, gy, s);
             q = divs<Fast>(rad, fspp);                                          // :452 accrad / samps.y
         }
         // fold the round's S samples into the accumulator in sample order (every lane of the group
@@ -327,24 +395,40 @@ __global__ void __launch_bounds__(256) pathtrace_kernel(PTArgs a) {
 
 // Launch helpers implemented once per math mode (pathtrace_fast.hip / pathtrace_strict.hip).
 // variant: 0 = generic (run-time object counts), 1 = slab-specialised 6 planes + 3 spheres.
-int launch_fast(const PTArgs& a, int variant, int S, uint32_t tile_rows, hipStream_t s);
-int launch_strict(const PTArgs& a, int variant, int S, uint32_t tile_rows, hipStream_t s);
+// prec: 0 = fp32 sphere test (the reference's default build); 1/2/3 = native fp64 / DS / DF64 branch (generic kernel,
+// S in {1,16} only).
+int launch_fast(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s);
+int launch_strict(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s);
+
+template <bool Fast, int NP, int NS, bool Slab, int S, int Prec>
+inline void launch_one(const PTArgs& a, uint32_t tile_rows, hipStream_t s) {
+    dim3 grid((a.W + block_w<S>() - 1u) / block_w<S>(), (tile_rows + block_h<S>() - 1u) / block_h<S>());
+    hipLaunchKernelGGL((pathtrace_kernel<Fast, NP, NS, Slab, S, Prec>), grid, dim3(256), 0, s, a);
+}
 
 template <bool Fast>
-inline int launch_impl(const PTArgs& a, int variant, int S, uint32_t tile_rows, hipStream_t s) {
-#define MC_PT_LAUNCH(SVAL)                                                                                          \
-    {                                                                                                               \
-        dim3 grid((a.W + block_w<SVAL>() - 1u) / block_w<SVAL>(), (tile_rows + block_h<SVAL>() - 1u) / block_h<SVAL>()); \
-        if (variant == 1) hipLaunchKernelGGL((pathtrace_kernel<Fast, 6, 3, true, SVAL>), grid, dim3(256), 0, s, a);   \
-        else hipLaunchKernelGGL((pathtrace_kernel<Fast, -1, -1, false, SVAL>), grid, dim3(256), 0, s, a);             \
+inline int launch_impl(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s) {
+    if (prec == 0) {
+        if (variant == 1) {
+            if (S == 1) launch_one<Fast, 6, 3, true, 1, 0>(a, tile_rows, s);
+            else if (S == 4) launch_one<Fast, 6, 3, true, 4, 0>(a, tile_rows, s);
+            else if (S == 16) launch_one<Fast, 6, 3, true, 16, 0>(a, tile_rows, s);
+            else return MC_ERR_INVALID_ARGUMENT;
+        } else {
+            if (S == 1) launch_one<Fast, -1, -1, false, 1, 0>(a, tile_rows, s);
+            else if (S == 4) launch_one<Fast, -1, -1, false, 4, 0>(a, tile_rows, s);
+            else if (S == 16) launch_one<Fast, -1, -1, false, 16, 0>(a, tile_rows, s);
+            else return MC_ERR_INVALID_ARGUMENT;
+        }
+        return MC_OK;
     }
-    switch (S) {
-        case 1: MC_PT_LAUNCH(1) break;
-        case 4: MC_PT_LAUNCH(4) break;
-        case 16: MC_PT_LAUNCH(16) break;
+    if (S != 1 && S != 16) return MC_ERR_INVALID_ARGUMENT;
+    switch (prec) {
+        case 1: if (S == 1) launch_one<Fast, -1, -1, false, 1, 1>(a, tile_rows, s); else launch_one<Fast, -1, -1, false, 16, 1>(a, tile_rows, s); break;
+        case 2: if (S == 1) launch_one<Fast, -1, -1, false, 1, 2>(a, tile_rows, s); else launch_one<Fast, -1, -1, false, 16, 2>(a, tile_rows, s); break;
+        case 3: if (S == 1) launch_one<Fast, -1, -1, false, 1, 3>(a, tile_rows, s); else launch_one<Fast, -1, -1, false, 16, 3>(a, tile_rows, s); break;
         default: return MC_ERR_INVALID_ARGUMENT;
     }
-#undef MC_PT_LAUNCH
     return MC_OK;
 }
 

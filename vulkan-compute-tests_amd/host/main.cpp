@@ -3,7 +3,8 @@
 // Mandelbrot app renders 2000x2000; lifecycle init() -> preRun() -> run() -> saveRenderedImage();
 // std::runtime_error -> message + EXIT_FAILURE.  Options (never reinterpreting the two positional
 // arguments) expose what the reference hard-codes: --gpus N, --out FILE, --quiet, and per mode
-// --width/--height/--max-iter/--centre X Y/--scale SX SY/--precision f32|ds  or  --math strict|fast.
+// --width/--height/--max-iter/--centre X Y/--scale SX SY/--precision f32|ds  or  --math strict|fast,
+// --large-sphere-walls, --sphere-precision f32|fp64|ds|df64 (the reference's compile-time precision experiment).
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -31,7 +32,8 @@ int main(int argc, char* argv[]) {
     const char* outFile = nullptr;
     uint32_t width = 2000, height = 2000, maxIter = 128, precision = MC_PRECISION_F32, mathMode = MC_PT_MATH_STRICT;
     double cx = -0.445, cy = 0.0, sx = 2.34, sy = 2.34;
-    bool viewSet = false;
+    bool viewSet = false, largeSpheres = false;
+    uint32_t spherePrec = MC_PT_PREC_F32;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto need = [&](int n) { if (i + n >= argc) { printf("missing value for %s\n", a.c_str()); exit(EXIT_FAILURE); } };
@@ -45,9 +47,14 @@ int main(int argc, char* argv[]) {
         else if (a == "--scale") { need(2); sx = atof(argv[++i]); sy = atof(argv[++i]); viewSet = true; }
         else if (a == "--precision") { need(1); precision = std::strcmp(argv[++i], "ds") == 0 ? MC_PRECISION_DS : MC_PRECISION_F32; }
         else if (a == "--math") { need(1); mathMode = std::strcmp(argv[++i], "fast") == 0 ? MC_PT_MATH_FAST : MC_PT_MATH_STRICT; }
+        else if (a == "--large-sphere-walls") largeSpheres = true;   // TEST_PRECISION_WITH_LARGE_SPHERE_WALLS (pathtracerApp.h:11)
+        else if (a == "--sphere-precision") {                        // which #if branch of pathTracer.comp:132-256 is active
+            need(1); std::string v = argv[++i];
+            spherePrec = v == "fp64" ? MC_PT_PREC_FP64 : v == "ds" ? MC_PT_PREC_DS : v == "df64" ? MC_PT_PREC_DF64 : MC_PT_PREC_F32;
+        }
         else pos.push_back(argv[i]);
     }
-    (void)width; (void)height; (void)maxIter; (void)precision; (void)mathMode; (void)cx; (void)cy; (void)sx; (void)sy; (void)viewSet;
+    (void)width; (void)height; (void)maxIter; (void)precision; (void)mathMode; (void)cx; (void)cy; (void)sx; (void)sy; (void)viewSet; (void)largeSpheres; (void)spherePrec;
 
 #if defined(MANDELBROT_MODE)
     MandelbrotApp app = MandelbrotApp(width, height);   // reference: 2000 x 2000 (main.cpp:20)
@@ -60,6 +67,8 @@ int main(int argc, char* argv[]) {
     const uint32_t resx = resy * 3 / 2;                                                // horizontal pixel resolution
     PathtracerApp app = PathtracerApp(resx, resy, spp);
     app.setMathMode(mathMode);
+    if (largeSpheres) app.useLargeSphereWalls();
+    app.setSpherePrecision(spherePrec);
 #endif
     app.setNumGpus(gpus);
     app.setQuiet(quiet);

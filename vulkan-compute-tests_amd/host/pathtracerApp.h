@@ -35,6 +35,24 @@ struct PathtracerApp : public ComputeApp {
 
     // -- additions --
     void setMathMode(uint32_t mode) { params.math_mode = mode; }   // MC_PT_MATH_STRICT / MC_PT_MATH_FAST
+    // The reference's precision experiment (pathtracerApp.h:11, emulateDouble.h.glsl:13-26), a run-time switch here:
+    // which sphere-test branch of pathTracer.comp:132-256 is active, and the sphere-walled scene of :28-35.
+    void setSpherePrecision(uint32_t prec) { params.flags = (params.flags & ~MC_PT_PRECISION(0xf)) | MC_PT_PRECISION(prec); }
+    void useLargeSphereWalls() {
+        static const float dummyPlane[12] = {1, 0, 0, 1000, 0, 0, 0, 0, 1, 1, 1, 1};   // "must have at least one plane" (:22-23)
+        static const float walls[6 * 12] = {
+            (float)(1e5 - 2.6), 0, 0, (float)1e5, 0, 0, 0, 0, (float).85, (float).25, (float).25, 1,    // Left
+            (float)(1e5 + 2.6), 0, 0, (float)1e5, 0, 0, 0, 0, (float).25, (float).35, (float).85, 1,    // Right
+            0, (float)(1e5 + 2), 0, (float)1e5, 0, 0, 0, 0, (float).75, (float).75, (float).75, 1,      // Top
+            0, (float)(-1e5 - 2), 0, (float)1e5, 0, 0, 0, 0, (float).75, (float).75, (float).75, 1,     // Bottom
+            0, 0, (float)(-1e5 - 2.8), (float)1e5, 0, 0, 0, 0, (float).85, (float).85, (float).25, 1,   // Back
+            0, 0, (float)(1e5 + 7.9), (float)1e5, 0, 0, 0, 0, (float)0.1, (float)0.7, (float)0.7, 1,    // Front
+        };
+        std::vector<float> sp(walls, walls + 72);
+        sp.insert(sp.end(), spheres.begin(), spheres.end());   // then mirror, glass, light (:36-38)
+        planes.assign(dummyPlane, dummyPlane + 12);
+        spheres.swap(sp);
+    }
     void setScene(const float* pl, uint32_t np, const float* sp, uint32_t ns) {
         planes.assign(pl, pl + 12 * np);
         spheres.assign(sp, sp + 12 * ns);
