@@ -181,6 +181,7 @@ int mc_context_destroy(mc_context* ctx) {
     ctx->scratch_rgba.release();
     ctx->scratch_iters.release();
     ctx->scratch_u8.release();
+    ctx->scene_buf.release();
     delete ctx;
     return MC_OK;
 }

@@ -42,6 +42,9 @@ struct mc_context {
     float lut_kcolor[4] = {0, 0, 0, 0};
     // scratch for the host-buffer entry points
     mc::DeviceBuffer scratch_rgba, scratch_iters, scratch_u8;
+    // generic path-tracer scenes: device copy of [records | emissive indices] and the host copy it mirrors
+    mc::DeviceBuffer scene_buf;
+    std::vector<float> scene_host;
 };
 
 namespace mc {

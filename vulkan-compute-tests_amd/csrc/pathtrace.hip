@@ -64,8 +64,8 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
         return MC_ERR_INVALID_ARGUMENT;
     if (p->math_mode != MC_PT_MATH_STRICT && p->math_mode != MC_PT_MATH_FAST) return MC_ERR_INVALID_ARGUMENT;
     if (p->row_stride && (!p->row_block || p->row_block > p->row_stride)) return MC_ERR_INVALID_ARGUMENT;
-    if (n_planes > (uint32_t)pt::kMaxPlanes || n_spheres > (uint32_t)pt::kMaxSpheres) {
-        set_error_detail("scene exceeds the on-chip scene store (16 planes + 16 spheres)");
+    if (((size_t)n_planes + n_spheres) * 48u + (size_t)n_spheres * 4u > pt::kMaxSceneLdsBytes) {
+        set_error_detail("scene exceeds the LDS-resident scene store (about 3000 objects)");
         return MC_ERR_UNSUPPORTED;
     }
     PTArgs a;
@@ -83,17 +83,41 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
     a.lc = h_add(a.cam_o, h_muls(a.cam_d, 0.035f));
     a.out = (float4*)d_rgba;
     a.scene.n_planes = n_planes; a.scene.n_spheres = n_spheres;
-    if (n_planes) std::memcpy(a.scene.obj, planes, sizeof(float) * 12 * n_planes);
-    if (n_spheres) std::memcpy(a.scene.obj + 12 * n_planes, spheres, sizeof(float) * 12 * n_spheres);
-    for (uint32_t i = 0; i < n_spheres; i++) {
-        const float* sp = spheres + 12 * i;
-        a.scene.r2[i] = sp[3] * sp[3];
-        v3 e{sp[4], sp[5], sp[6]};
-        if (h_dot(e, e) > 0.0f) a.scene.emissive_mask |= 1u << i;
-    }
     const int prec = (int)((p->flags >> 16) & 0xfu);   // MC_PT_PRECISION(x)
     if (prec > 3) return MC_ERR_INVALID_ARGUMENT;
     const bool slab = prec == 0 && analyse_slabs(planes, n_planes, n_spheres, a.scene) && !(p->flags & MC_PT_GENERIC_KERNEL);
+    if (slab) {   // 6 planes + 3 spheres: the records travel in the kernel-argument segment
+        std::memcpy(a.scene.obj, planes, sizeof(float) * 12 * n_planes);
+        std::memcpy(a.scene.obj + 12 * n_planes, spheres, sizeof(float) * 12 * n_spheres);
+        for (uint32_t i = 0; i < n_spheres; i++) {
+            const float* sp = spheres + 12 * i;
+            a.scene.r2[i] = sp[3] * sp[3];
+            v3 e{sp[4], sp[5], sp[6]};
+            if (h_dot(e, e) > 0.0f) a.scene.emissive_mask |= 1u << i;
+        }
+    } else {      // any other scene: device buffer [records | emissive sphere indices], staged into LDS by the kernel
+        std::vector<float> host((size_t)(n_planes + n_spheres) * 12 + n_spheres);
+        if (n_planes) std::memcpy(host.data(), planes, sizeof(float) * 12 * n_planes);
+        if (n_spheres) std::memcpy(host.data() + 12 * (size_t)n_planes, spheres, sizeof(float) * 12 * n_spheres);
+        uint32_t* em = reinterpret_cast<uint32_t*>(host.data() + (size_t)(n_planes + n_spheres) * 12);
+        uint32_t n_em = 0;
+        for (uint32_t i = 0; i < n_spheres; i++) {
+            const float* sp = spheres + 12 * i;
+            v3 e{sp[4], sp[5], sp[6]};
+            if (h_dot(e, e) > 0.0f) em[n_em++] = i;                      // pathTracer.comp:407
+        }
+        host.resize((size_t)(n_planes + n_spheres) * 12 + n_em);
+        if (host != ctx->scene_host || !ctx->scene_buf.ptr) {            // upload only when the scene changed
+            MC_HIP_TRY(hipDeviceSynchronize());                          // an earlier launch may still read the old copy
+            int rc = ctx->scene_buf.reserve(host.size() * sizeof(float) + 16);
+            if (rc) return rc;
+            MC_HIP_TRY(hipMemcpy(ctx->scene_buf.ptr, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+            ctx->scene_host = host;
+        }
+        a.scene.d_obj = (const float*)ctx->scene_buf.ptr;
+        a.scene.d_emissive = (const uint32_t*)((const float*)ctx->scene_buf.ptr + (size_t)(n_planes + n_spheres) * 12);
+        a.scene.n_emissive = n_em;
+    }
     const uint32_t rows = tile_rows(p->row_begin, p->row_end, a.row_block, a.row_stride);
     int S = (int)((p->flags >> 8) & 0xffu);   // MC_PT_FORCE_S(s)
     if (S == 0) S = choose_S((uint64_t)rows * p->width, p->sample_end - p->sample_begin);

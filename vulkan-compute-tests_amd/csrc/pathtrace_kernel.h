@@ -57,6 +57,13 @@ struct SceneArgs {
     // is +e_axis ("pos") and -e_axis ("neg"): offset w and plane index, index < 0 when absent.
     float slab_w_pos[3], slab_w_neg[3];
     int32_t slab_id_pos[3], slab_id_neg[3];
+    // Generic kernels (any scene): the 12-float records (planes, then spheres) and the list of emissive sphere
+    // indices live in a device buffer and are staged into dynamic LDS by every block — obj[]/r2[]/emissive_mask
+    // above are then unused.  Capacity is bounded by the 160 KB of LDS per CU, not by the kernel-argument segment.
+    const float* d_obj;
+    const uint32_t* d_emissive;
+    uint32_t n_emissive;
+    uint32_t pad2;
 };
 
 struct PTArgs {
@@ -162,9 +169,12 @@ __device__ __forceinline__ bool sphere_extended(const float* sp, float r2, v3 o,
 }
 
 // intersect — pathTracer.comp:112-131 + :316-341.  Returns the hit object id (planes 0..NP-1, spheres
-// NP..NP+NS-1) or -1, and the ray parameter.  NP/NS < 0 select run-time counts.
+// NP..NP+NS-1) or -1, and the ray parameter.  NP/NS < 0 select run-time counts; `obj` is the record array the
+// loops read with wave-uniform indices: the kernel-argument copy (SGPR operands) for the specialised kernels,
+// the LDS copy (broadcast ds_reads) for the generic ones.
 template <bool Fast, int NP, int NS, bool Slab, int Prec>
-__device__ __forceinline__ int intersect(const SceneArgs& sc, v3 o, v3 d, float& t_out) {
+__device__ __forceinline__ int intersect(const SceneArgs& sc, const float* __restrict__ obj, v3 o, v3 d, float& t_out) {
+    constexpr bool LdsScene = NP < 0;
     const int np = NP >= 0 ? NP : (int)sc.n_planes;
     const int ns = NS >= 0 ? NS : (int)sc.n_spheres;
     float t = kInf;
@@ -189,7 +199,7 @@ __device__ __forceinline__ int intersect(const SceneArgs& sc, v3 o, v3 d, float&
     } else {
 #pragma unroll
         for (int i = 0; i < np; i++) {
-            const float* pl = sc.obj + 12 * i;
+            const float* pl = obj + 12 * i;
             v3 n{pl[0], pl[1], pl[2]};
             float denom = dot(d, n);                                         // :118
             if (denom > kTriEps) {                                           // :119
@@ -200,18 +210,19 @@ __device__ __forceinline__ int intersect(const SceneArgs& sc, v3 o, v3 d, float&
     }
 #pragma unroll
     for (int i = 0; i < ns; i++) {
-        const float* sp = sc.obj + 12 * (np + i);
+        const float* sp = obj + 12 * (np + i);
+        const float r2 = LdsScene ? sp[3] * sp[3] : sc.r2[i];   // the fp32 product of :318 either way
         bool extended = false;
         if (Prec != 0) {
             extended = needs_precision(sp, o);
             if (extended) {
                 float dd;
-                if (sphere_extended<Fast, Prec>(sp, sc.r2[i], o, d, dd) && dd < t) { t = dd; id = np + i; }   // :333
+                if (sphere_extended<Fast, Prec>(sp, r2, o, d, dd) && dd < t) { t = dd; id = np + i; }   // :333
             }
         }
         v3 oc = v3{sp[0], sp[1], sp[2]} - o;                                 // :317
         float b = dot(oc, d);                                                // :318
-        float det = (b * b - dot(oc, oc)) + sc.r2[i];
+        float det = (b * b - dot(oc, oc)) + r2;
         if (!extended && !(det < 0.0f)) {                                    // :319
             float sq = dm::fsqrt<Fast>(det);
             float dd = b - sq;                                               // :322,324
@@ -228,9 +239,11 @@ __device__ __forceinline__ int intersect(const SceneArgs& sc, v3 o, v3 d, float&
 
 // One sample: returns accrad (pathTracer.comp:356-449).
 template <bool Fast, int NP, int NS, bool Slab, int Prec>
-__device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restrict__ lds_obj, uint32_t gx, uint32_t gy,
-                                           uint32_t samp) {
+__device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restrict__ lds_obj,
+                                           const uint32_t* __restrict__ lds_emissive, uint32_t gx, uint32_t gy, uint32_t samp) {
     const SceneArgs& sc = a.scene;
+    constexpr bool LdsScene = NP < 0;
+    const float* __restrict__ uobj = LdsScene ? lds_obj : sc.obj;   // records read with wave-uniform indices
     const int np = NP >= 0 ? NP : (int)sc.n_planes;
     const int ns = NS >= 0 ? NS : (int)sc.n_spheres;
     // -- sample sensor (:357-362)
@@ -248,7 +261,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
 
     for (uint32_t depth = 0; depth < a.max_depth; depth++) {              // :367
         float t;
-        int id = intersect<Fast, NP, NS, Slab, Prec>(sc, ro, rd, t);
+        int id = intersect<Fast, NP, NS, Slab, Prec>(sc, uobj, ro, rd, t);
         if (id < 0) break;   // :369 `continue` with an unchanged ray misses again at every later depth: no effect
         v3 x = ro + rd * t;                                               // :374 (o + t*d: fp32 mul is commutative)
         const float* obj = lds_obj + 12 * id;                             // per-lane fetch from LDS
@@ -268,15 +281,19 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             accmat = divs<Fast>(accmat, p);                               // :397
         }
         if (mat == 1) {                                                   // :400 diffuse
-            for (int i = 0; i < ns; i++) {                                // :403
-                if (!((sc.emissive_mask >> i) & 1u)) continue;            // :407 (uniform)
-                const float* ls = sc.obj + 12 * (np + i);
+            const int n_lights = LdsScene ? (int)sc.n_emissive : ns;
+            for (int k = 0; k < n_lights; k++) {                          // :403
+                int i = k;
+                if (LdsScene) i = (int)lds_emissive[k];                   // host-built list of the spheres passing :407
+                else if (!((sc.emissive_mask >> i) & 1u)) continue;       // :407 (uniform)
+                const float* ls = uobj + 12 * (np + i);
+                const float lr2 = LdsScene ? ls[3] * ls[3] : sc.r2[i];
                 v3 le{ls[4], ls[5], ls[6]};
                 v3 xc = v3{ls[0], ls[1], ls[2]} - x;                      // :408
                 v3 sw = normalize<Fast>(xc);                              // :409
                 v3 su = normalize<Fast>(cross((__builtin_fabsf(sw.x) > 0.1f ? v3{0, 1, 0} : v3{1, 0, 0}), sw));
                 v3 sv = cross(sw, su);
-                float cos_a_max = dm::fsqrt<Fast>(1.0f - dm::fdiv<Fast>(sc.r2[i], dot(xc, xc)));   // :410
+                float cos_a_max = dm::fsqrt<Fast>(1.0f - dm::fdiv<Fast>(lr2, dot(xc, xc)));   // :410
                 float cos_a = (1.0f - rnd.x) + rnd.x * cos_a_max;         // :411
                 float sin_a = dm::fsqrt<Fast>(1.0f - cos_a * cos_a);
                 float phi = (2.0f * kPi) * rnd.y;                         // :412
@@ -284,7 +301,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 dm::sincos_angle<Fast>(phi, rnd.y, sphi, cphi);
                 v3 l = normalize<Fast>(((su * cphi) * sin_a + (sv * sphi) * sin_a) + sw * cos_a);   // :413
                 float tne;
-                int idne = intersect<Fast, NP, NS, Slab, Prec>(sc, x, l, tne);  // :420 shadow ray
+                int idne = intersect<Fast, NP, NS, Slab, Prec>(sc, uobj, x, l, tne);  // :420 shadow ray
                 if (idne == np + i) {
                     float omega = (2.0f * kPi) * (1.0f - cos_a_max);      // :421
                     accrad = accrad + ((divs<Fast>(accmat, kPi) * dm::gmax(dot(l, nl), 0.0f)) * le) * omega;   // :422
@@ -346,9 +363,15 @@ template <int S> constexpr uint32_t block_h() { return 2u * WaveTile<S>::h; }
 
 template <bool Fast, int NP, int NS, bool Slab, int S, int Prec>
 __global__ void __launch_bounds__(256) pathtrace_kernel(PTArgs a) {
-    __shared__ float lds_obj[(kMaxPlanes + kMaxSpheres) * 12];
-    {
-        const uint32_t count = (a.scene.n_planes + a.scene.n_spheres) * 12u;
+    // dynamic LDS (no static __shared__ in front: the base stays 16-B aligned): [records | emissive list]
+    extern __shared__ float lds_dyn[];
+    float* lds_obj = lds_dyn;
+    const uint32_t count = (a.scene.n_planes + a.scene.n_spheres) * 12u;
+    uint32_t* lds_emissive = reinterpret_cast<uint32_t*>(lds_dyn + count);
+    if (NP < 0) {   // generic: stage from the device buffer
+        for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) lds_obj[i] = a.scene.d_obj[i];
+        for (uint32_t i = threadIdx.x; i < a.scene.n_emissive; i += blockDim.x) lds_emissive[i] = a.scene.d_emissive[i];
+    } else {        // specialised: stage the kernel-argument copy for the per-lane material fetch
         for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) lds_obj[i] = a.scene.obj[i];
     }
     __syncthreads();
@@ -370,7 +393,7 @@ __global__ void __launch_bounds__(256) pathtrace_kernel(PTArgs a) {
         const uint32_t s = base + j;
         v3 q{0.0f, 0.0f, 0.0f};
         if (valid && s < a.sample_end) {
-            v3 rad = trace_sample<Fast, NP, NS, Slab, Prec>(a, lds_obj, gx, gy, s);
+            v3 rad = trace_sample<Fast, NP, NS, Slab, Prec>(a, lds_obj, lds_emissive, gx, gy, s);
             q = divs<Fast>(rad, fspp);                                          // :452 accrad / samps.y
         }
         // fold the round's S samples into the accumulator in sample order (every lane of the group
@@ -400,10 +423,19 @@ __global__ void __launch_bounds__(256) pathtrace_kernel(PTArgs a) {
 int launch_fast(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s);
 int launch_strict(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s);
 
+inline size_t scene_lds_bytes(const PTArgs& a) {
+    return ((size_t)(a.scene.n_planes + a.scene.n_spheres) * 12u + a.scene.n_emissive) * sizeof(float);
+}
+constexpr size_t kMaxSceneLdsBytes = 144u * 1024u;   // of the 160 KB per CU: 3072 objects
+
 template <bool Fast, int NP, int NS, bool Slab, int S, int Prec>
 inline void launch_one(const PTArgs& a, uint32_t tile_rows, hipStream_t s) {
     dim3 grid((a.W + block_w<S>() - 1u) / block_w<S>(), (tile_rows + block_h<S>() - 1u) / block_h<S>());
-    hipLaunchKernelGGL((pathtrace_kernel<Fast, NP, NS, Slab, S, Prec>), grid, dim3(256), 0, s, a);
+    const size_t lds = scene_lds_bytes(a);
+    auto kern = pathtrace_kernel<Fast, NP, NS, Slab, S, Prec>;
+    if (lds > 48u * 1024u)   // beyond the default dynamic-LDS window: opt in (gfx950 has 160 KB per CU)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
 }
 
 template <bool Fast>
