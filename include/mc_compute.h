@@ -155,6 +155,13 @@ int mc_convert_rgba8_device_async(mc_context* ctx, const void* d_rgba_f32, uint3
                                   float scale, int rotate180, void* d_rgba8, void* stream);
 int mc_convert_rgba8(mc_context* ctx, const float* rgba_f32, uint32_t width, uint32_t height, float scale,
                      int rotate180, uint8_t* rgba8);
+/* Render + post-process fused on the device: the whole image is rendered, converted exactly as the reference's
+ * saveRenderedImage would (Mandelbrot: scale 255, mandelbrotApp.h:159-174; path tracer: scale 1 and the
+ * 180-degree rotation, pathtracerApp.h:202-243) and only the RGBA8 image (4 B/pixel instead of 16) is copied to
+ * out_rgba8 (width*height*4 bytes, host).  Whole image only (row_begin = 0, row_end = height, no interleave). */
+int mc_mandelbrot_render_rgba8(mc_context* ctx, const mc_mandelbrot_params* p, uint8_t* out_rgba8);
+int mc_pathtrace_render_rgba8(mc_context* ctx, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
+                              const float* spheres, uint32_t n_spheres, uint8_t* out_rgba8);
 
 /* ---- stream / tiling helpers ------------------------------------------------------------------ */
 int mc_context_synchronize(mc_context* ctx);
@@ -177,6 +184,10 @@ int mc_multi_destroy(mc_multi* m);
 int mc_multi_mandelbrot_render(mc_multi* m, const mc_mandelbrot_params* p, float* out_rgba_f32, uint32_t* out_iters);
 int mc_multi_pathtrace_render(mc_multi* m, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
                               const float* spheres, uint32_t n_spheres, float* out_rgba_f32);
+/* As mc_*_render_rgba8: the assembled storage buffer is converted on device 0 and only RGBA8 leaves the GPU. */
+int mc_multi_mandelbrot_render_rgba8(mc_multi* m, const mc_mandelbrot_params* p, uint8_t* out_rgba8);
+int mc_multi_pathtrace_render_rgba8(mc_multi* m, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
+                                    const float* spheres, uint32_t n_spheres, uint8_t* out_rgba8);
 
 /* ---- device self-tests used by the parity suite (evaluate device functions over arrays) --------- */
 /* fn: 0 mc_sin, 1 mc_cos, 2 mc_log2, 3 mc_exp2, 4 pow(x,0.45), 5 inversesqrt, 6 sqrt, 7 1/x,

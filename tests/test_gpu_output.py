@@ -1,0 +1,98 @@
+"""GPU tests of the fused render + post-process entry points (mc_*_render_rgba8) and of the apps' end-to-end
+options: the RGBA8 image produced on the device equals the reference's host post-process of the storage buffer."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rgba8(B, ctx, fn, *args):
+    return fn(ctx._h, *args)
+
+
+def test_render_rgba8_equals_host_postprocess(ctx, B, O):
+    L = B.lib()
+    L.mc_mandelbrot_render_rgba8.argtypes = [C.c_void_p, C.POINTER(B.MandelbrotParams), C.c_void_p]
+    L.mc_pathtrace_render_rgba8.argtypes = [C.c_void_p, C.POINTER(B.PathtraceParams), C.c_void_p, C.c_uint32, C.c_void_p,
+                                            C.c_uint32, C.c_void_p]
+    # Mandelbrot
+    W, H, M = 333, 211, 200
+    p = B.mandelbrot_params(W, H, max_iter=M)
+    out = np.empty((H, W, 4), np.uint8)
+    assert L.mc_mandelbrot_render_rgba8(ctx._h, C.byref(p), out.ctypes.data_as(C.c_void_p)) == 0
+    _, lut_u8 = O.mandel_lut(M)
+    assert np.array_equal(out, lut_u8[O.mandelbrot_iters(W, H, M)])
+    # path tracer (odd width: the reference's middle-column quirk included)
+    for W, H in ((48, 32), (51, 30)):
+        q = B.pathtrace_params(W, H, 5)
+        planes, spheres = B.default_scene()
+        out = np.empty((H, W, 4), np.uint8)
+        assert L.mc_pathtrace_render_rgba8(ctx._h, C.byref(q), planes.ctypes.data_as(C.c_void_p), 6,
+                                           spheres.ctypes.data_as(C.c_void_p), 3, out.ctypes.data_as(C.c_void_p)) == 0
+        ref = O.pathtrace(W, H, 5, math_mode=O.MATH_MC)
+        assert np.array_equal(out, O.rotate180(O.float_to_rgba8(ref, 1.0).reshape(H, W, 4), W, H))
+    # tiles / partial sample ranges are rejected
+    q = B.pathtrace_params(48, 32, 5, sample_end=3)
+    assert L.mc_pathtrace_render_rgba8(ctx._h, C.byref(q), planes.ctypes.data_as(C.c_void_p), 6,
+                                       spheres.ctypes.data_as(C.c_void_p), 3, out.ctypes.data_as(C.c_void_p)) == 1
+
+
+def test_multi_rgba8_one_device(ctx, B, O, monkeypatch):
+    L = B.lib()
+    L.mc_multi_mandelbrot_render_rgba8.argtypes = [C.c_void_p, C.POINTER(B.MandelbrotParams), C.c_void_p]
+    L.mc_multi_pathtrace_render_rgba8.argtypes = [C.c_void_p, C.POINTER(B.PathtraceParams), C.c_void_p, C.c_uint32, C.c_void_p,
+                                                  C.c_uint32, C.c_void_p]
+    monkeypatch.setenv("MC_MULTI_FORCE_RCCL", "1")
+    with B.Multi(1) as m:
+        p = B.mandelbrot_params(200, 120, max_iter=150)
+        out = np.empty((120, 200, 4), np.uint8)
+        assert L.mc_multi_mandelbrot_render_rgba8(m._h, C.byref(p), out.ctypes.data_as(C.c_void_p)) == 0
+        _, lut_u8 = O.mandel_lut(150)
+        assert np.array_equal(out, lut_u8[O.mandelbrot_iters(200, 120, 150)])
+        q = B.pathtrace_params(40, 24, 4)
+        planes, spheres = B.default_scene()
+        out = np.empty((24, 40, 4), np.uint8)
+        assert L.mc_multi_pathtrace_render_rgba8(m._h, C.byref(q), planes.ctypes.data_as(C.c_void_p), 6,
+                                                 spheres.ctypes.data_as(C.c_void_p), 3, out.ctypes.data_as(C.c_void_p)) == 0
+        ref = O.pathtrace(40, 24, 4, math_mode=O.MATH_MC)
+        assert np.array_equal(out, O.rotate180(O.float_to_rgba8(ref, 1.0).reshape(24, 40, 4), 40, 24))
+
+
+def test_apps_gpu_postprocess_and_precision_options(B, O, tmp_path):
+    from PIL import Image
+    bindir = os.path.join(os.path.dirname(os.path.dirname(B.LIB_PATH)), "bin")
+    # same PNG pixels with and without the device-side post-process, serial and parallel deflate
+    imgs = []
+    for extra in ([], ["--gpu-postprocess"], ["--gpu-postprocess", "--png-threads", "1"], ["--gpus", "1", "--gpu-postprocess"]):
+        r = subprocess.run([os.path.join(bindir, "pathtracer"), "4", "40", "--out", "o.png", "--quiet"] + extra,
+                           capture_output=True, text=True, cwd=tmp_path)
+        assert r.returncode == 0, r.stdout + r.stderr
+        imgs.append(np.asarray(Image.open(tmp_path / "o.png").convert("RGBA")))
+    ref = O.pathtrace(60, 40, 4, math_mode=O.MATH_MC)
+    exp = O.rotate180(O.float_to_rgba8(ref, 1.0).reshape(40, 60, 4), 60, 40)
+    for im in imgs:
+        assert np.array_equal(im, exp)
+    r = subprocess.run([os.path.join(bindir, "mandelbrot"), "--width", "300", "--height", "200", "--gpu-postprocess", "--quiet"],
+                       capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0
+    _, lut_u8 = O.mandel_lut(128)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "mandelbrot.png").convert("RGBA")), lut_u8[O.mandelbrot_iters(300, 200, 128)])
+    # the precision experiment from the command line
+    r = subprocess.run([os.path.join(bindir, "pathtracer"), "4", "32", "--large-sphere-walls", "--sphere-precision", "ds", "--quiet"],
+                       capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0
+    img = np.asarray(Image.open(tmp_path / "pathtracer.png").convert("RGBA"))
+    ref = O.pathtrace(48, 32, 4, planes=O.LARGE_SPHERE_PLANES, spheres=O.LARGE_SPHERE_SPHERES, math_mode=O.MATH_MC, precision=O.PREC_DS)
+    assert np.array_equal(img, O.rotate180(O.float_to_rgba8(ref, 1.0).reshape(32, 48, 4), 48, 32))
+    # Mandelbrot two-float from the command line
+    r = subprocess.run([os.path.join(bindir, "mandelbrot"), "--width", "64", "--height", "48", "--max-iter", "600", "--precision", "ds",
+                        "--centre", "-0.7436438870371587", "0.13182590420531198", "--scale", "1e-8", "6.666666666666667e-9", "--quiet"],
+                       capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0
+    _, lut_u8 = O.mandel_lut(600)
+    it = O.mandelbrot_iters(64, 48, 600, view=O.make_view(-0.7436438870371587, 0.13182590420531198, 1e-8, 6.666666666666667e-9), precision=1)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "mandelbrot.png").convert("RGBA")), lut_u8[it])

@@ -1,0 +1,79 @@
+"""CPU tests of the parallel PNG writer (host/pngWriter.cpp): row stripes deflated by several
+threads and concatenated into one zlib stream must decode to the same pixels as the serial encoding, for every
+thread count, stripe layout and colour type."""
+import ctypes as C
+import io
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def H(B):
+    lib = C.CDLL(os.path.join(os.path.dirname(B.LIB_PATH), "libmc_hostutil.so"))
+    lib.mcu_png_encode_mt.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_size_t)]
+    lib.mcu_free.argtypes = [C.c_void_p]
+    return lib
+
+
+def encode(H, img, threads):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape[:2]
+    out, n = C.POINTER(C.c_ubyte)(), C.c_size_t(0)
+    assert H.mcu_png_encode_mt(img.ctypes.data_as(C.c_void_p), w, h, threads, C.byref(out), C.byref(n)) == 0
+    data = C.string_at(out, n.value)
+    H.mcu_free(out)
+    return data
+
+
+def decode(data):
+    from PIL import Image
+    return np.asarray(Image.open(io.BytesIO(data)).convert("RGBA"))
+
+
+def idat_payload(data):
+    pos, out = 8, b""
+    while pos < len(data):
+        ln = int.from_bytes(data[pos:pos + 4], "big")
+        typ = data[pos + 4:pos + 8]
+        assert zlib.crc32(data[pos + 4:pos + 8 + ln]) == int.from_bytes(data[pos + 8 + ln:pos + 12 + ln], "big")
+        if typ == b"IDAT":
+            out += data[pos + 8:pos + 8 + ln]
+        pos += 12 + ln
+    return out
+
+
+@pytest.mark.parametrize("shape", [(600, 900), (1, 1), (3, 5000), (2000, 17), (257, 263)])
+def test_parallel_png_equals_serial_pixels(H, O, shape):
+    h, w = shape
+    rng = np.random.default_rng(h * 7 + w)
+    smooth = (np.add.outer(np.arange(h), np.arange(w)) % 256).astype(np.uint8)
+    img = np.stack([smooth, smooth[::-1], rng.integers(0, 256, (h, w), dtype=np.uint8), np.full((h, w), 255, np.uint8)], -1)
+    serial = encode(H, img, 1)
+    assert np.array_equal(decode(serial), img)
+    for threads in (2, 3, 8, 0):
+        data = encode(H, img, threads)
+        assert np.array_equal(decode(data), img), threads
+        # the concatenated stripes form ONE valid zlib stream with a correct combined Adler-32
+        raw = zlib.decompress(idat_payload(data))
+        assert len(raw) == h * (w * 3 + 1)
+        if O.ref_lodepng() is not None:       # and the reference's own decoder accepts it
+            assert np.array_equal(O.ref_png_decode(data), img)
+
+
+def test_parallel_png_with_alpha(H):
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (300, 200, 4), dtype=np.uint8)
+    for threads in (1, 4):
+        assert np.array_equal(decode(encode(H, img, threads)), img)
+
+
+def test_parallel_png_large_image_is_faster_or_equal_size_sane(H, O):
+    """A Mandelbrot-like 3200x2400 image: stripe-parallel output stays within 2 % of the serial size."""
+    _, lut_u8 = O.mandel_lut(256)
+    img = np.ascontiguousarray(lut_u8[O.mandelbrot_iters(1600, 1200, 256)])
+    a, b = encode(H, img, 1), encode(H, img, 8)
+    assert np.array_equal(decode(b), img)
+    assert len(b) < len(a) * 1.02 + 4096

@@ -329,6 +329,43 @@ int mc_convert_rgba8(mc_context* ctx, const float* rgba_f32, uint32_t width, uin
     return MC_OK;
 }
 
+// ---- render + post-process fused on the device ------------------------------------------------------------
+static int download_rgba8(mc_context* ctx, uint32_t W, uint32_t H, float scale, int rotate180, uint8_t* out_rgba8) {
+    const size_t npix = (size_t)W * H;
+    int rc = ctx->scratch_u8.reserve(npix * 4);
+    if (rc) return rc;
+    rc = convert_rgba8_launch(ctx, ctx->scratch_rgba.ptr, W, H, scale, rotate180, ctx->scratch_u8.ptr, ctx->stream);
+    if (rc) return rc;
+    MC_HIP_TRY(hipMemcpyAsync(out_rgba8, ctx->scratch_u8.ptr, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MC_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MC_OK;
+}
+
+int mc_mandelbrot_render_rgba8(mc_context* ctx, const mc_mandelbrot_params* p, uint8_t* out_rgba8) {
+    if (!ctx || !p || !out_rgba8) return MC_ERR_INVALID_ARGUMENT;
+    if (p->row_begin != 0 || p->row_end != p->height || p->row_stride || !p->width || !p->height) return MC_ERR_INVALID_ARGUMENT;
+    MC_HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ctx->scratch_rgba.reserve((size_t)p->width * p->height * 16);
+    if (rc) return rc;
+    rc = mandelbrot_launch(ctx, p, ctx->scratch_rgba.ptr, nullptr, ctx->stream);
+    if (rc) return rc;
+    return download_rgba8(ctx, p->width, p->height, 255.0f, 0, out_rgba8);      // mandelbrotApp.h:159-174
+}
+
+int mc_pathtrace_render_rgba8(mc_context* ctx, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
+                              const float* spheres, uint32_t n_spheres, uint8_t* out_rgba8) {
+    if (!ctx || !p || !out_rgba8) return MC_ERR_INVALID_ARGUMENT;
+    if (p->row_begin != 0 || p->row_end != p->height || p->row_stride || p->sample_begin != 0 || p->sample_end != p->spp ||
+        !p->width || !p->height)
+        return MC_ERR_INVALID_ARGUMENT;
+    MC_HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ctx->scratch_rgba.reserve((size_t)p->width * p->height * 16);
+    if (rc) return rc;
+    rc = pathtrace_launch(ctx, p, planes, n_planes, spheres, n_spheres, ctx->scratch_rgba.ptr, ctx->stream);
+    if (rc) return rc;
+    return download_rgba8(ctx, p->width, p->height, 1.0f, 1, out_rgba8);        // pathtracerApp.h:202-243
+}
+
 // ---- device self-tests ------------------------------------------------------------------------------
 static int run_test(mc_context* ctx, const void* in_a, size_t bytes_a, const void* in_b, size_t bytes_b, void* out,
                     size_t bytes_out, void (*launch)(void*, void*, void*, size_t, hipStream_t, int, int), size_t n, int p0,

@@ -21,7 +21,7 @@ struct mc_multi {
     std::vector<mc_context*> ctx;
     std::vector<ncclComm_t> comms;
     std::vector<mc::DeviceBuffer> tile_rgba, tile_iters;
-    mc::DeviceBuffer gather_rgba, gather_iters, full_rgba, full_iters;   // on device 0
+    mc::DeviceBuffer gather_rgba, gather_iters, full_rgba, full_iters, full_u8;   // on device 0
     bool use_rccl = false;
 };
 
@@ -129,15 +129,17 @@ int mc_multi_destroy(mc_multi* m) {
     }
     if (m->n && m->ctx[0]) {
         (void)hipSetDevice(m->ctx[0]->device);
-        m->gather_rgba.release(); m->gather_iters.release(); m->full_rgba.release(); m->full_iters.release();
+        m->gather_rgba.release(); m->gather_iters.release(); m->full_rgba.release(); m->full_iters.release(); m->full_u8.release();
     }
     for (int i = 0; i < m->n; i++) mc_context_destroy(m->ctx[i]);
     delete m;
     return MC_OK;
 }
 
-int mc_multi_mandelbrot_render(mc_multi* m, const mc_mandelbrot_params* p, float* out_rgba_f32, uint32_t* out_iters) {
-    if (!m || !p || (!out_rgba_f32 && !out_iters)) return MC_ERR_INVALID_ARGUMENT;
+static int multi_mandelbrot(mc_multi* m, const mc_mandelbrot_params* p, float* out_rgba_f32, uint32_t* out_iters,
+                            uint8_t* out_rgba8) {
+    if (!m || !p || (!out_rgba_f32 && !out_iters && !out_rgba8)) return MC_ERR_INVALID_ARGUMENT;
+    const bool want_rgba = out_rgba_f32 || out_rgba8;
     if (p->row_begin != 0 || p->row_end != p->height || p->row_stride) return MC_ERR_INVALID_ARGUMENT;   // whole image only
     if ((p->width % 4u) != 0 && out_iters && m->n > 1) return MC_ERR_UNSUPPORTED;   // 16-B row granules for the u32 plane
     const uint32_t W = p->width, H = p->height;
@@ -146,20 +148,26 @@ int mc_multi_mandelbrot_render(mc_multi* m, const mc_mandelbrot_params* p, float
     for (int i = 0; i < m->n; i++) {
         mc_context* c = m->ctx[i];
         MC_HIP_TRY(hipSetDevice(c->device));
-        if (out_rgba_f32 && (rc = m->tile_rgba[i].reserve((size_t)padded * W * 16))) return rc;
+        if (want_rgba && (rc = m->tile_rgba[i].reserve((size_t)padded * W * 16))) return rc;
         if (out_iters && (rc = m->tile_iters[i].reserve((size_t)padded * W * 4))) return rc;
         mc_mandelbrot_params q = *p;
         q.row_begin = (uint32_t)i * kRowBlock; q.row_end = H;
         q.row_block = kRowBlock; q.row_stride = kRowBlock * (uint32_t)m->n;
         if (q.row_begin >= H) continue;   // more GPUs than row blocks
-        rc = mandelbrot_launch(c, &q, out_rgba_f32 ? m->tile_rgba[i].ptr : nullptr, out_iters ? m->tile_iters[i].ptr : nullptr,
+        rc = mandelbrot_launch(c, &q, want_rgba ? m->tile_rgba[i].ptr : nullptr, out_iters ? m->tile_iters[i].ptr : nullptr,
                                c->stream);
         if (rc) return rc;
     }
     mc_context* c0 = m->ctx[0];
-    if (out_rgba_f32) {
+    if (want_rgba) {
         if ((rc = gather_and_assemble(m, m->tile_rgba, m->gather_rgba, m->full_rgba, W, H, padded, 16))) return rc;
-        MC_HIP_TRY(hipMemcpyAsync(out_rgba_f32, m->full_rgba.ptr, (size_t)W * H * 16, hipMemcpyDeviceToHost, c0->stream));
+        if (out_rgba_f32)
+            MC_HIP_TRY(hipMemcpyAsync(out_rgba_f32, m->full_rgba.ptr, (size_t)W * H * 16, hipMemcpyDeviceToHost, c0->stream));
+        if (out_rgba8) {   // mandelbrotApp.h:159-174 on device 0: only 4 B/pixel leave the GPU
+            if ((rc = m->full_u8.reserve((size_t)W * H * 4))) return rc;
+            if ((rc = convert_rgba8_launch(c0, m->full_rgba.ptr, W, H, 255.0f, 0, m->full_u8.ptr, c0->stream))) return rc;
+            MC_HIP_TRY(hipMemcpyAsync(out_rgba8, m->full_u8.ptr, (size_t)W * H * 4, hipMemcpyDeviceToHost, c0->stream));
+        }
     }
     if (out_iters) {
         if ((rc = gather_and_assemble(m, m->tile_iters, m->gather_iters, m->full_iters, W, H, padded, 4))) return rc;
@@ -172,9 +180,18 @@ int mc_multi_mandelbrot_render(mc_multi* m, const mc_mandelbrot_params* p, float
     return MC_OK;
 }
 
-int mc_multi_pathtrace_render(mc_multi* m, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
-                              const float* spheres, uint32_t n_spheres, float* out_rgba_f32) {
-    if (!m || !p || !out_rgba_f32) return MC_ERR_INVALID_ARGUMENT;
+int mc_multi_mandelbrot_render(mc_multi* m, const mc_mandelbrot_params* p, float* out_rgba_f32, uint32_t* out_iters) {
+    if (!out_rgba_f32 && !out_iters) return MC_ERR_INVALID_ARGUMENT;
+    return multi_mandelbrot(m, p, out_rgba_f32, out_iters, nullptr);
+}
+int mc_multi_mandelbrot_render_rgba8(mc_multi* m, const mc_mandelbrot_params* p, uint8_t* out_rgba8) {
+    if (!out_rgba8) return MC_ERR_INVALID_ARGUMENT;
+    return multi_mandelbrot(m, p, nullptr, nullptr, out_rgba8);
+}
+
+static int multi_pathtrace(mc_multi* m, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
+                           const float* spheres, uint32_t n_spheres, float* out_rgba_f32, uint8_t* out_rgba8) {
+    if (!m || !p || (!out_rgba_f32 && !out_rgba8)) return MC_ERR_INVALID_ARGUMENT;
     if (p->row_begin != 0 || p->row_end != p->height || p->row_stride) return MC_ERR_INVALID_ARGUMENT;
     if (p->sample_begin != 0) return MC_ERR_UNSUPPORTED;   // progressive continuation: single-GPU entry points
     const uint32_t W = p->width, H = p->height;
@@ -193,12 +210,30 @@ int mc_multi_pathtrace_render(mc_multi* m, const mc_pathtrace_params* p, const f
     }
     if ((rc = gather_and_assemble(m, m->tile_rgba, m->gather_rgba, m->full_rgba, W, H, padded, 16))) return rc;
     mc_context* c0 = m->ctx[0];
-    MC_HIP_TRY(hipMemcpyAsync(out_rgba_f32, m->full_rgba.ptr, (size_t)W * H * 16, hipMemcpyDeviceToHost, c0->stream));
+    if (out_rgba_f32)
+        MC_HIP_TRY(hipMemcpyAsync(out_rgba_f32, m->full_rgba.ptr, (size_t)W * H * 16, hipMemcpyDeviceToHost, c0->stream));
+    if (out_rgba8) {   // pathtracerApp.h:202-243 on device 0
+        if (p->sample_end != p->spp) return MC_ERR_INVALID_ARGUMENT;
+        if ((rc = m->full_u8.reserve((size_t)W * H * 4))) return rc;
+        if ((rc = convert_rgba8_launch(c0, m->full_rgba.ptr, W, H, 1.0f, 1, m->full_u8.ptr, c0->stream))) return rc;
+        MC_HIP_TRY(hipMemcpyAsync(out_rgba8, m->full_u8.ptr, (size_t)W * H * 4, hipMemcpyDeviceToHost, c0->stream));
+    }
     for (int i = 0; i < m->n; i++) {
         MC_HIP_TRY(hipSetDevice(m->ctx[i]->device));
         MC_HIP_TRY(hipStreamSynchronize(m->ctx[i]->stream));
     }
     return MC_OK;
+}
+
+int mc_multi_pathtrace_render(mc_multi* m, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
+                              const float* spheres, uint32_t n_spheres, float* out_rgba_f32) {
+    if (!out_rgba_f32) return MC_ERR_INVALID_ARGUMENT;
+    return multi_pathtrace(m, p, planes, n_planes, spheres, n_spheres, out_rgba_f32, nullptr);
+}
+int mc_multi_pathtrace_render_rgba8(mc_multi* m, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
+                                    const float* spheres, uint32_t n_spheres, uint8_t* out_rgba8) {
+    if (!out_rgba8) return MC_ERR_INVALID_ARGUMENT;
+    return multi_pathtrace(m, p, planes, n_planes, spheres, n_spheres, nullptr, out_rgba8);
 }
 
 }  // extern "C"

@@ -38,6 +38,10 @@ struct ComputeApp {
     void setNumGpus(int n) { numGpus = n < 1 ? 1 : n; }   // row-tiled multi-GPU render + RCCL gather
     void setDevice(int d) { deviceIndex = d; }
     void setQuiet(bool q) { quiet = q; }
+    // float->u8 conversion (+ rotation) on the device so only RGBA8 crosses PCIe; the fp32 storage buffer is then
+    // not copied to the host (storageBuffer() stays empty).  Same cast semantics, same bytes.
+    void setGpuPostprocess(bool g) { gpuPostprocess = g; }
+    void setPngThreads(int t) { pngThreads = t; }   // 0 = all cores, 1 = serial deflate
     double lastRunMilliseconds() const { return lastRunMs; }
 
 protected:
@@ -49,6 +53,9 @@ protected:
     int numGpus = 1;
     int deviceIndex = 0;   // the reference always takes devices[0] (vulkanComputeApp.cpp:163)
     bool quiet = false;
+    bool gpuPostprocess = false;
+    int pngThreads = 0;
+    std::vector<uint8_t> rgba8;   // filled by run() when gpuPostprocess is on
     double lastRunMs = 0.0;
     // The storage buffer, host side: vec4 fp32 per pixel, row-major (what vkMapMemory exposes to
     // getRenderedImage in the reference).

@@ -7,15 +7,18 @@
 
 extern "C" {
 
-// Encodes RGBA8 into a malloc'ed PNG; caller frees with mcu_free.  Returns 0 on success.
-int mcu_png_encode(const uint8_t* rgba8, uint32_t w, uint32_t h, uint8_t** out, size_t* out_len) {
+// Encodes RGBA8 into a malloc'ed PNG with `threads` deflate workers (0 = all cores); caller frees with mcu_free.
+int mcu_png_encode_mt(const uint8_t* rgba8, uint32_t w, uint32_t h, int threads, uint8_t** out, size_t* out_len) {
     std::vector<uint8_t> png;
-    if (!pngwriter::encode(png, rgba8, w, h).empty()) return 1;
+    if (!pngwriter::encode(png, rgba8, w, h, threads).empty()) return 1;
     *out = (uint8_t*)std::malloc(png.size());
     if (!*out) return 2;
     std::memcpy(*out, png.data(), png.size());
     *out_len = png.size();
     return 0;
+}
+int mcu_png_encode(const uint8_t* rgba8, uint32_t w, uint32_t h, uint8_t** out, size_t* out_len) {
+    return mcu_png_encode_mt(rgba8, w, h, 0, out, out_len);
 }
 void mcu_free(void* p) { std::free(p); }
 

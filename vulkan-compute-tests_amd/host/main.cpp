@@ -5,6 +5,7 @@
 // arguments) expose what the reference hard-codes: --gpus N, --out FILE, --quiet, and per mode
 // --width/--height/--max-iter/--centre X Y/--scale SX SY/--precision f32|ds  or  --math strict|fast,
 // --large-sphere-walls, --sphere-precision f32|fp64|ds|df64 (the reference's compile-time precision experiment).
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -28,7 +29,8 @@ int main(int argc, char* argv[]) {
     // split options from positional arguments
     std::vector<const char*> pos;
     int gpus = 1;
-    bool quiet = false;
+    bool quiet = false, gpuPost = false;
+    int pngThreads = 0;
     const char* outFile = nullptr;
     uint32_t width = 2000, height = 2000, maxIter = 128, precision = MC_PRECISION_F32, mathMode = MC_PT_MATH_STRICT;
     double cx = -0.445, cy = 0.0, sx = 2.34, sy = 2.34;
@@ -40,6 +42,8 @@ int main(int argc, char* argv[]) {
         if (a == "--gpus") { need(1); gpus = atoi(argv[++i]); }
         else if (a == "--out") { need(1); outFile = argv[++i]; }
         else if (a == "--quiet") quiet = true;
+        else if (a == "--gpu-postprocess") gpuPost = true;     // float->u8 (+rotation) on the device, RGBA8-only download
+        else if (a == "--png-threads") { need(1); pngThreads = atoi(argv[++i]); }   // 0 = all cores (default), 1 = serial
         else if (a == "--width") { need(1); width = (uint32_t)atoi(argv[++i]); }
         else if (a == "--height") { need(1); height = (uint32_t)atoi(argv[++i]); }
         else if (a == "--max-iter") { need(1); maxIter = (uint32_t)atoi(argv[++i]); }
@@ -72,6 +76,8 @@ int main(int argc, char* argv[]) {
 #endif
     app.setNumGpus(gpus);
     app.setQuiet(quiet);
+    app.setGpuPostprocess(gpuPost);
+    app.setPngThreads(pngThreads);
 
     try {
         // the reference calls init()/preRun() outside its try block (main.cpp:28-29); a missing device
@@ -80,8 +86,11 @@ int main(int argc, char* argv[]) {
         app.preRun();
         printf("now running app!\n");
         app.run();
+        auto t0 = std::chrono::steady_clock::now();
         if (outFile) app.saveRenderedImage(outFile);
         else app.saveRenderedImage();
+        double saveMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (!quiet) printf("saveRenderedImage() finished in %.3f ms\n", saveMs);
     } catch (const std::runtime_error& e) {
         printf("%s\n", e.what());
         return EXIT_FAILURE;

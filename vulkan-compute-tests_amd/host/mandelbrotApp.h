@@ -39,6 +39,12 @@ struct MandelbrotApp : public ComputeApp {
     }
 
     virtual void runCommandBuffer() override {
+        if (gpuPostprocess) {   // render + float->u8 on the device: 4 B/pixel cross PCIe instead of 16
+            rgba8.resize((size_t)resx * resy * 4);
+            if (multi) check(mc_multi_mandelbrot_render_rgba8(multi, &params, rgba8.data()), "mc_multi_mandelbrot_render_rgba8");
+            else check(mc_mandelbrot_render_rgba8(ctx, &params, rgba8.data()), "mc_mandelbrot_render_rgba8");
+            return;
+        }
         if (multi) check(mc_multi_mandelbrot_render(multi, &params, buffer.data(), nullptr), "mc_multi_mandelbrot_render");
         else check(mc_mandelbrot_render(ctx, &params, buffer.data(), nullptr), "mc_mandelbrot_render");
     }
@@ -59,9 +65,10 @@ struct MandelbrotApp : public ComputeApp {
     virtual void saveRenderedImage(const char* png_filename = "mandelbrot.png") override {
         std::vector<uint8_t> image;
         constexpr float scaleFactor = 255.0f;   // mandelbrotApp.h:174
-        getRenderedImage(image, resx, resy, scaleFactor);
+        if (gpuPostprocess) image.swap(rgba8);  // already converted on the device with the same cast semantics
+        else getRenderedImage(image, resx, resy, scaleFactor);
         printf("writing %s\n", png_filename);
-        std::string err = pngwriter::encodeFile(png_filename, image.data(), resx, resy);
+        std::string err = pngwriter::encodeFile(png_filename, image.data(), resx, resy, pngThreads);
         if (!err.empty()) printf("encoder error: %s", err.c_str());   // printed, not thrown (mandelbrotApp.h:183)
     }
 

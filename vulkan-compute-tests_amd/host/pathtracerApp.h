@@ -76,6 +76,15 @@ struct PathtracerApp : public ComputeApp {
     }
 
     virtual void runCommandBuffer() override {
+        if (gpuPostprocess) {   // render + float->u8 + 180-degree rotation on the device (pathtracerApp.h:202-243)
+            rgba8.resize((size_t)resx * resy * 4);
+            const uint32_t np = (uint32_t)planes.size() / 12, ns = (uint32_t)spheres.size() / 12;
+            if (multi) check(mc_multi_pathtrace_render_rgba8(multi, &params, planes.data(), np, spheres.data(), ns, rgba8.data()),
+                             "mc_multi_pathtrace_render_rgba8");
+            else check(mc_pathtrace_render_rgba8(ctx, &params, planes.data(), np, spheres.data(), ns, rgba8.data()),
+                       "mc_pathtrace_render_rgba8");
+            return;
+        }
         if (multi)
             check(mc_multi_pathtrace_render(multi, &params, planes.data(), (uint32_t)planes.size() / 12, spheres.data(),
                                             (uint32_t)spheres.size() / 12, buffer.data()), "mc_multi_pathtrace_render");
@@ -99,18 +108,22 @@ struct PathtracerApp : public ComputeApp {
     virtual void saveRenderedImage(const char* png_filename = "pathtracer.png") override {
         std::vector<uint8_t> image;
         constexpr float scaleFactor = 1.0f;   // pathtracerApp.h:227
-        getRenderedImage(image, resx, resy, scaleFactor);
         printf("writing %s\n", png_filename);
-        // due to the pinhole camera the image is upside-down and mirrored — undo that (pathtracerApp.h:235-243)
-        uint32_t* pRGBA = reinterpret_cast<uint32_t*>(image.data());
-        for (uint32_t y = 0; y < resy; y++) {
-            for (uint32_t x = 0; x < resx / 2; x++) {
-                uint32_t from = x + y * resx;
-                uint32_t to = (resx - 1) - x + ((resy - 1) - y) * resx;
-                std::swap(pRGBA[from], pRGBA[to]);
+        if (gpuPostprocess) {
+            image.swap(rgba8);   // converted and rotated on the device
+        } else {
+            getRenderedImage(image, resx, resy, scaleFactor);
+            // due to the pinhole camera the image is upside-down and mirrored — undo that (pathtracerApp.h:235-243)
+            uint32_t* pRGBA = reinterpret_cast<uint32_t*>(image.data());
+            for (uint32_t y = 0; y < resy; y++) {
+                for (uint32_t x = 0; x < resx / 2; x++) {
+                    uint32_t from = x + y * resx;
+                    uint32_t to = (resx - 1) - x + ((resy - 1) - y) * resx;
+                    std::swap(pRGBA[from], pRGBA[to]);
+                }
             }
         }
-        std::string err = pngwriter::encodeFile(png_filename, image.data(), resx, resy);
+        std::string err = pngwriter::encodeFile(png_filename, image.data(), resx, resy, pngThreads);
         if (!err.empty()) printf("encoder error: %s", err.c_str());
     }
 

@@ -2,9 +2,12 @@
 
 #include <zlib.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace pngwriter {
 
@@ -14,13 +17,20 @@ void put32(std::vector<uint8_t>& v, uint32_t x) {
     v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
 }
 
-void chunk(std::vector<uint8_t>& out, const char type[4], const uint8_t* data, size_t len) {
+void chunk_header_and_crc(std::vector<uint8_t>& out, const char type[4], const uint8_t* data, size_t len) {
     put32(out, (uint32_t)len);
     size_t start = out.size();
     out.insert(out.end(), type, type + 4);
     if (len) out.insert(out.end(), data, data + len);
-    uint32_t c = (uint32_t)crc32(0L, out.data() + start, (uInt)(len + 4));
-    put32(out, c);
+    uLong c = crc32(0L, out.data() + start, 4);
+    // crc32 takes a 32-bit length: feed large IDAT payloads in pieces
+    size_t pos = start + 4, left = len;
+    while (left) {
+        uInt n = (uInt)std::min<size_t>(left, 1u << 30);
+        c = crc32(c, out.data() + pos, n);
+        pos += n; left -= n;
+    }
+    put32(out, (uint32_t)c);
 }
 
 inline int paeth(int a, int b, int c) {
@@ -28,20 +38,19 @@ inline int paeth(int a, int b, int c) {
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
-}  // namespace
-
-std::string encode(std::vector<uint8_t>& out, const uint8_t* rgba8, uint32_t w, uint32_t h) {
-    if (!rgba8 || !w || !h) return "empty image";
-    bool opaque = true;
-    for (size_t i = 0; i < (size_t)w * h && opaque; i++) opaque = rgba8[4 * i + 3] == 255;
-    const int bpp = opaque ? 3 : 4;
+// Filters rows [y0,y1) of the RGBA8 image into `raw` ((stride+1) bytes per row): per row the PNG filter with the
+// smallest sum of absolute residuals.  Row y needs row y-1 of the SOURCE image only, so stripes are independent.
+void filter_rows(const uint8_t* rgba8, uint32_t w, uint32_t y0, uint32_t y1, int bpp, uint8_t* raw) {
     const size_t stride = (size_t)w * bpp;
-    // filtered scanlines: per row pick the filter with the smallest sum of absolute residuals
-    std::vector<uint8_t> raw((stride + 1) * h);
     std::vector<uint8_t> cur(stride), prev(stride, 0), cand(stride), best(stride);
-    for (uint32_t y = 0; y < h; y++) {
+    auto load = [&](uint32_t y, std::vector<uint8_t>& dst) {
         const uint8_t* src = rgba8 + (size_t)y * w * 4;
-        for (uint32_t x = 0; x < w; x++) std::memcpy(&cur[(size_t)x * bpp], src + 4 * (size_t)x, bpp);
+        if (bpp == 4) std::memcpy(dst.data(), src, stride);
+        else for (uint32_t x = 0; x < w; x++) std::memcpy(&dst[(size_t)x * 3], src + 4 * (size_t)x, 3);
+    };
+    if (y0 > 0) load(y0 - 1, prev);
+    for (uint32_t y = y0; y < y1; y++) {
+        load(y, cur);
         uint64_t best_sum = ~0ull;
         int best_f = 0;
         for (int f = 0; f < 5; f++) {
@@ -55,29 +64,110 @@ std::string encode(std::vector<uint8_t>& out, const uint8_t* rgba8, uint32_t w, 
             }
             if (sum < best_sum) { best_sum = sum; best_f = f; best.swap(cand); }
         }
-        uint8_t* dst = &raw[(stride + 1) * y];
+        uint8_t* dst = raw + (stride + 1) * (size_t)(y - y0);
         dst[0] = (uint8_t)best_f;
         std::memcpy(dst + 1, best.data(), stride);
-        prev = cur;
+        prev.swap(cur);
     }
-    uLongf zlen = compressBound((uLong)raw.size());
-    std::vector<uint8_t> z(zlen);
-    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return "zlib compress2 failed";
+}
+
+struct Stripe {
+    uint32_t y0 = 0, y1 = 0;
+    std::vector<uint8_t> z;   // raw deflate bytes of this stripe (sync-flushed, or finished for the last one)
+    uLong adler = 1;
+    size_t raw_len = 0;
+    bool ok = false;
+};
+
+// One stripe: filter + raw deflate.  Non-final stripes end on a byte boundary with Z_SYNC_FLUSH (an empty stored
+// block), so the concatenation of all stripes is ONE valid deflate stream (the pigz construction).
+void compress_stripe(const uint8_t* rgba8, uint32_t w, int bpp, bool last, Stripe& s) {
+    const size_t stride = (size_t)w * bpp;
+    std::vector<uint8_t> raw((stride + 1) * (size_t)(s.y1 - s.y0));
+    filter_rows(rgba8, w, s.y0, s.y1, bpp, raw.data());
+    s.raw_len = raw.size();
+    uLong ad = adler32(0L, Z_NULL, 0);
+    for (size_t pos = 0; pos < raw.size();) {
+        uInt n = (uInt)std::min<size_t>(raw.size() - pos, 1u << 30);
+        ad = adler32(ad, raw.data() + pos, n);
+        pos += n;
+    }
+    s.adler = ad;
+    z_stream zs;
+    std::memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return;
+    s.z.resize(deflateBound(&zs, (uLong)raw.size()) + 16);
+    zs.next_in = raw.data(); zs.avail_in = (uInt)raw.size();
+    zs.next_out = s.z.data(); zs.avail_out = (uInt)s.z.size();
+    int rc = deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);
+    s.ok = last ? rc == Z_STREAM_END : (rc == Z_OK && zs.avail_in == 0);
+    s.z.resize(s.z.size() - zs.avail_out);
+    deflateEnd(&zs);
+}
+
+}  // namespace
+
+std::string encode(std::vector<uint8_t>& out, const uint8_t* rgba8, uint32_t w, uint32_t h, int threads) {
+    if (!rgba8 || !w || !h) return "empty image";
+    bool opaque = true;
+    for (size_t i = 0; i < (size_t)w * h && opaque; i++) opaque = rgba8[4 * i + 3] == 255;
+    const int bpp = opaque ? 3 : 4;
+    // stripes of >= 64 KiB of raw data, at most 4 per worker thread
+    if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    threads = std::max(1, std::min(threads, 64));
+    const size_t row_bytes = (size_t)w * bpp + 1;
+    uint32_t min_rows = (uint32_t)std::max<size_t>(1, (64 * 1024 + row_bytes - 1) / row_bytes);
+    uint32_t n_stripes = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)threads * 4u, h / min_rows ? h / min_rows : 1));
+    if (threads == 1) n_stripes = 1;
+    std::vector<Stripe> stripes(n_stripes);
+    for (uint32_t i = 0; i < n_stripes; i++) {
+        stripes[i].y0 = (uint32_t)((uint64_t)h * i / n_stripes);
+        stripes[i].y1 = (uint32_t)((uint64_t)h * (i + 1) / n_stripes);
+    }
+    std::atomic<uint32_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            uint32_t i = next.fetch_add(1);
+            if (i >= n_stripes) break;
+            compress_stripe(rgba8, w, bpp, i + 1 == n_stripes, stripes[i]);
+        }
+    };
+    int nt = (int)std::min<uint32_t>((uint32_t)threads, n_stripes);
+    if (nt <= 1) worker();
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; t++) th.emplace_back(worker);
+        for (auto& t : th) t.join();
+    }
+    size_t zlen = 2 + 4;
+    uLong adler = adler32(0L, Z_NULL, 0);
+    for (auto& s : stripes) {
+        if (!s.ok) return "zlib deflate failed";
+        zlen += s.z.size();
+        adler = adler32_combine(adler, s.adler, (z_off_t)s.raw_len);
+    }
+    std::vector<uint8_t> z;
+    z.reserve(zlen);
+    z.push_back(0x78); z.push_back(0x9c);   // zlib header: deflate, 32 KiB window, default compression
+    for (auto& s : stripes) z.insert(z.end(), s.z.begin(), s.z.end());
+    put32(z, (uint32_t)adler);
+
     out.clear();
+    out.reserve(z.size() + 64);
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     out.insert(out.end(), sig, sig + 8);
     std::vector<uint8_t> ihdr;
     put32(ihdr, w); put32(ihdr, h);
     ihdr.push_back(8); ihdr.push_back(opaque ? 2 : 6); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
-    chunk(out, "IHDR", ihdr.data(), ihdr.size());
-    chunk(out, "IDAT", z.data(), zlen);
-    chunk(out, "IEND", nullptr, 0);
+    chunk_header_and_crc(out, "IHDR", ihdr.data(), ihdr.size());
+    chunk_header_and_crc(out, "IDAT", z.data(), z.size());
+    chunk_header_and_crc(out, "IEND", nullptr, 0);
     return "";
 }
 
-std::string encodeFile(const char* filename, const uint8_t* rgba8, uint32_t w, uint32_t h) {
+std::string encodeFile(const char* filename, const uint8_t* rgba8, uint32_t w, uint32_t h, int threads) {
     std::vector<uint8_t> png;
-    std::string err = encode(png, rgba8, w, h);
+    std::string err = encode(png, rgba8, w, h, threads);
     if (!err.empty()) return err;
     FILE* f = std::fopen(filename, "wb");
     if (!f) return std::string("cannot open ") + filename;
