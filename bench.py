@@ -46,6 +46,27 @@ K1 = dict(W=3200, H=2400, M=1000)
 K4_VIEW = dict(centre=(-0.7436438870371587, 0.13182590420531198), scale=(1e-8, 1e-8 * 2.0 / 3.0))
 
 
+def profiled_traffic(wl, args, n):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC pass committed under profiles/
+    (WRITE_SIZE in its own --pmc pass; exact for 16-B-per-lane stores, MI355X_MICROARCH.md §HBM; these kernels
+    read nothing but a <1 MB LUT / 432 B of scene).  None when the run is not the profiled default configuration."""
+    if n != 1 or args.width or args.height or args.spp:
+        return None
+    tag = {"pathtrace": "pt_fast" if args.math == "fast" else "pt_strict", "mandelbrot": "mandel",
+           "mandelbrot_ds": "mandel_ds"}[wl]
+    for rnd in ("r01c", "r01b"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}_pmc_summary.json")
+        if os.path.exists(path):
+            try:
+                for entry in json.load(open(path)).values():
+                    b = entry.get("derived", {}).get("hbm_write_bytes")
+                    if b:
+                        return b
+            except (ValueError, OSError):
+                return None
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,8 +212,14 @@ def main():
                        "tiling": "whole image" if n == 1 else f"interleaved {ROW_BLOCK}-row blocks, RCCL gather to rank 0",
                        "device": dev_name, "compute_units": cus},
             "roofline": {"bound": "valu", "kernel": kern, "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_TFLOPS,
+                         "traffic": profiled_traffic(wl, args, n),
                          "kernel_ms": kernel_ms, "flops_per_unit": flops_per_unit,
+                         # HBM is not the bound: the algorithmic bytes are the 16-B storage-buffer entry per pixel
+                         # (+4 B iteration count for Mandelbrot), written once
+                         "hbm": {"algorithmic_bytes": W * rows_local * (16 if wl == "pathtrace" else 20),
+                                 "gbps": W * rows_local * (16 if wl == "pathtrace" else 20) / (kernel_ms * 1e-3) / 1e9,
+                                 "peak_gbps": 8000.0},
                          "lane_ops": {"achieved": achieved_tflops * 1e12, "peak": PEAK_LANE_OPS,
                                       "frac": achieved_tflops * 1e12 / PEAK_LANE_OPS,
                                       "note": "parity forbids contraction: one issue slot per flop"}},
