@@ -86,8 +86,12 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
     const int prec = (int)((p->flags >> 16) & 0xfu);   // MC_PT_PRECISION(x)
     if (prec > 3) return MC_ERR_INVALID_ARGUMENT;
     const bool slab = prec == 0 && analyse_slabs(planes, n_planes, n_spheres, a.scene) && !(p->flags & MC_PT_GENERIC_KERNEL);
-    if (slab) {   // 6 planes + 3 spheres: the records travel in the kernel-argument segment
-        std::memcpy(a.scene.obj, planes, sizeof(float) * 12 * n_planes);
+    if (slab) {   // 6 planes + 3 spheres: the records travel in the kernel-argument segment, planes in canonical
+                  // slab order (x-,x+,y-,y+,z-,z+) so that the kernel's plane id is 2*axis + (d[axis] > 0)
+        for (int ax = 0; ax < 3; ax++) {
+            std::memcpy(a.scene.obj + 12 * (2 * ax), planes + 12 * a.scene.slab_id_neg[ax], sizeof(float) * 12);
+            std::memcpy(a.scene.obj + 12 * (2 * ax + 1), planes + 12 * a.scene.slab_id_pos[ax], sizeof(float) * 12);
+        }
         std::memcpy(a.scene.obj + 12 * n_planes, spheres, sizeof(float) * 12 * n_spheres);
         for (uint32_t i = 0; i < n_spheres; i++) {
             const float* sp = spheres + 12 * i;

@@ -186,15 +186,17 @@ __device__ __forceinline__ int intersect(const SceneArgs& sc, const float* __res
         // pos: (w_pos - o[a]) / d[a];  neg: (w_neg - (-o[a])) / (-d[a]) = (w_neg + o[a]) / |d[a]|.
         // Axes are visited in plane-index order (host-checked), so `dd < t` resolves ties as the
         // reference's loop over planes does.  A NaN ray fails every test in both formulations.
+        // The host stores the six records in canonical slab order (x-,x+,y-,y+,z-,z+), so INSIDE the kernel the
+        // id of the plane of axis a that can face the ray is the compile-time pattern 2a + (d[a] > 0); ids never
+        // leave the kernel (they only index the record copy and tell planes from spheres).
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             const float da = comp(d, a), oa = comp(o, a);
             const bool pos = da > 0.0f;
             const float den = __builtin_fabsf(da);
             const float num = pos ? (sc.slab_w_pos[a] - oa) : (sc.slab_w_neg[a] + oa);
-            const int pid = pos ? sc.slab_id_pos[a] : sc.slab_id_neg[a];
             const float dd = dm::fdiv<Fast>(num, den);
-            if (den > kTriEps && pid >= 0 && dd < t) { t = dd; id = pid; }
+            if (den > kTriEps && dd < t) { t = dd; id = pos ? 2 * a + 1 : 2 * a; }
         }
     } else {
 #pragma unroll
