@@ -25,4 +25,10 @@ run("interior view M=10000 iters only", B.mandelbrot_params(W, H, max_iter=10000
 run("K1 view, both outputs", B.mandelbrot_params(W, H, max_iter=M), rg.data_ptr(), it.data_ptr())
 run("K1 view, iters only", B.mandelbrot_params(W, H, max_iter=M), 0, it.data_ptr())
 run("K1 view, rgba only", B.mandelbrot_params(W, H, max_iter=M), rg.data_ptr(), 0)
+rg2 = torch.empty((2000, 2000, 4), dtype=torch.float32, device="cuda"); it2 = torch.empty((2000, 2000), dtype=torch.int32, device="cuda")
+it = it2
+W, H = 2000, 2000
+run("reference default 2000x2000 M=128", B.mandelbrot_params(2000, 2000, max_iter=128), rg2.data_ptr(), it2.data_ptr(), reps=50)
+W, H = 3200, 2400
+it = torch.empty((H, W), dtype=torch.int32, device="cuda")
 run("exterior view (c far away)", B.mandelbrot_params(W, H, max_iter=M, centre=(3.0, 3.0), scale=(0.1, 0.1)), rg.data_ptr(), it.data_ptr())

@@ -178,6 +178,7 @@ int mc_context_destroy(mc_context* ctx) {
         (void)hipStreamDestroy(ctx->stream);
     }
     ctx->lut.release();
+    ctx->ctab.release();
     ctx->scratch_rgba.release();
     ctx->scratch_iters.release();
     ctx->scratch_u8.release();

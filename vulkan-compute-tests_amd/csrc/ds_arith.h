@@ -17,9 +17,12 @@ struct ds2 {
     float hi, lo;
 };
 
-__device__ __forceinline__ ds2 ds_set(float a) { return ds2{a, 0.0f}; }   // emulateDouble.h.glsl:59-64
+// ds_set / ds_add / ds_mul are also evaluated on the host (the per-column / per-row `c` tables of the two-float
+// Mandelbrot, mandelbrot.hip): the host pass is compiled with the same -ffp-contract=off, so both sides execute
+// the identical IEEE operation sequence.
+__host__ __device__ __forceinline__ ds2 ds_set(float a) { return ds2{a, 0.0f}; }   // emulateDouble.h.glsl:59-64
 
-__device__ __forceinline__ ds2 ds_add(ds2 a, ds2 b) {                      // :71-83
+__host__ __device__ __forceinline__ ds2 ds_add(ds2 a, ds2 b) {                      // :71-83
     float t1 = a.hi + b.hi;
     float e = t1 - a.hi;
     float t2 = ((b.hi - e) + (a.hi - (t1 - e))) + a.lo + b.lo;
@@ -58,7 +61,7 @@ __device__ __forceinline__ bool ds_greater(ds2 a, ds2 b) {
     return true;
 }
 
-__device__ __forceinline__ ds2 ds_mul(ds2 a, ds2 b) {                      // :114-139, split = 8193 (H2)
+__host__ __device__ __forceinline__ ds2 ds_mul(ds2 a, ds2 b) {                      // :114-139, split = 8193 (H2)
     const float split = 8193.0f;
     float cona = a.hi * split;
     float conb = b.hi * split;

@@ -37,6 +37,10 @@ struct MandelArgs {
     float4* __restrict__ out_rgba;      // tile-local, may be null
     uint32_t* __restrict__ out_iters;   // tile-local, may be null
     const float4* __restrict__ lut;     // max_iter+1 entries (null when out_rgba is null)
+    // c = centre + (uv - 0.5) * scale per column / per row, evaluated once on the host with the shader's fp32
+    // operation sequence (mandelbrot.comp:30-31,38): fp32 [cx[W] | cy[H]], two-float [cx(hi,lo)[W] | cy(hi,lo)[H]].
+    // Replaces two IEEE divisions (~50 instructions) per pixel; exterior tiles only run a handful of iterations.
+    const float* __restrict__ c_tab;
 };
 
 // ---- per-pixel state machines: step() advances one iteration and reports "escaped now" ----------
@@ -44,10 +48,8 @@ template <bool FMA>
 struct StateF32 {
     float cx, cy, zx, zy, sx, sy;   // sx = zx*zx, sy = zy*zy of the current z
     __device__ __forceinline__ void init(uint32_t gx, uint32_t gy, const MandelArgs& a) {
-        float x = (float)gx / (float)a.W;          // mandelbrot.comp:30
-        float y = (float)gy / (float)a.H;          // :31
-        cx = a.cx_hi + (x - 0.5f) * a.sx_hi;       // :38
-        cy = a.cy_hi + (y - 0.5f) * a.sy_hi;
+        cx = a.c_tab[gx];                          // mandelbrot.comp:30,38 (host-evaluated, see build_c_table)
+        cy = a.c_tab[a.W + gy];                    // :31,38
         zx = zy = sx = sy = 0.0f;
     }
     // One iteration (:43), returns |z|^2 = dot(z,z) of the new z (:44).
@@ -77,10 +79,10 @@ struct StateF32 {
 struct StateDS {
     ds2 cx, cy, zx, zy, sx, sy;
     __device__ __forceinline__ void init(uint32_t gx, uint32_t gy, const MandelArgs& a) {
-        float x = (float)gx / (float)a.W;
-        float y = (float)gy / (float)a.H;
-        cx = ds_add(ds2{a.cx_hi, a.cx_lo}, ds_mul(ds_set(x - 0.5f), ds2{a.sx_hi, a.sx_lo}));
-        cy = ds_add(ds2{a.cy_hi, a.cy_lo}, ds_mul(ds_set(y - 0.5f), ds2{a.sy_hi, a.sy_lo}));
+        const float2* tab = reinterpret_cast<const float2*>(a.c_tab);
+        float2 tx = tab[gx], ty = tab[a.W + gy];
+        cx = ds2{tx.x, tx.y};
+        cy = ds2{ty.x, ty.y};
         zx = zy = sx = sy = ds_set(0.0f);
     }
     static constexpr bool kHasBitFilter = false;   // 142 flops per iteration: the exact compare is noise
@@ -107,7 +109,7 @@ __device__ __forceinline__ uint32_t escape_time(State& st, uint32_t max_iter, bo
     uint32_t n = max_iter;
     uint32_t i = 0;
     for (; i + U <= max_iter; i += U) {
-        if (State::kHasBitFilter) {
+        if (State::kHasBitFilter && i != 0) {   // the first block is evaluated exactly: most tiles escape right there
             // fast path: U iterations of pure add/mul/or, ONE compare per block; the exact per-iteration
             // ballots below are evaluated (from the saved state) only if some unfinished lane may have escaped
             State probe = st;
@@ -200,6 +202,41 @@ static int ensure_lut(mc_context* ctx, const mc_mandelbrot_params* p, hipStream_
     return MC_OK;
 }
 
+// Per-column / per-row c tables.  x = float(gx)/float(W) (mandelbrot.comp:30), c.x = centre.x + (x - 0.5)*scale.x (:38) in
+// fp32 source order; the two-float variant composes ds_add(centre, ds_mul(ds_set(x - 0.5), scale)).
+// Host and device execute the same IEEE operations (no contraction), so the tables hold exactly the values the
+// kernel used to compute per pixel.  Cached in the context, keyed by (W, H, precision, view).
+static int ensure_c_table(mc_context* ctx, const mc_mandelbrot_params* p, hipStream_t s) {
+    std::vector<float> key = {(float)p->width, (float)p->height, (float)p->precision, p->centre_x_hi, p->centre_x_lo,
+                              p->centre_y_hi, p->centre_y_lo, p->scale_x_hi, p->scale_x_lo, p->scale_y_hi, p->scale_y_lo};
+    if (ctx->ctab.ptr && ctx->ctab_key.size() == key.size() &&
+        std::memcmp(ctx->ctab_key.data(), key.data(), key.size() * sizeof(float)) == 0)
+        return MC_OK;
+    const uint32_t W = p->width, H = p->height;
+    const bool ds = p->precision == MC_PRECISION_DS;
+    std::vector<float> tab(((size_t)W + H) * (ds ? 2 : 1));
+    for (uint32_t g = 0; g < W + H; g++) {
+        const bool is_x = g < W;
+        const float u = is_x ? (float)g / (float)W : (float)(g - W) / (float)H;
+        const float c_hi = is_x ? p->centre_x_hi : p->centre_y_hi, c_lo = is_x ? p->centre_x_lo : p->centre_y_lo;
+        const float s_hi = is_x ? p->scale_x_hi : p->scale_y_hi, s_lo = is_x ? p->scale_x_lo : p->scale_y_lo;
+        if (ds) {
+            ds2 c = ds_add(ds2{c_hi, c_lo}, ds_mul(ds_set(u - 0.5f), ds2{s_hi, s_lo}));
+            tab[2 * (size_t)g] = c.hi;
+            tab[2 * (size_t)g + 1] = c.lo;
+        } else {
+            tab[g] = c_hi + (u - 0.5f) * s_hi;
+        }
+    }
+    MC_HIP_TRY(hipDeviceSynchronize());   // an earlier launch may still read the old table
+    int rc = ctx->ctab.reserve(tab.size() * sizeof(float));
+    if (rc) return rc;
+    MC_HIP_TRY(hipMemcpyAsync(ctx->ctab.ptr, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    MC_HIP_TRY(hipStreamSynchronize(s));
+    ctx->ctab_key = key;
+    return MC_OK;
+}
+
 int mandelbrot_launch(mc_context* ctx, const mc_mandelbrot_params* p, void* d_rgba, void* d_iters, hipStream_t s) {
     if (!ctx || !p || (!d_rgba && !d_iters)) return MC_ERR_INVALID_ARGUMENT;
     if (!p->width || !p->height || !p->max_iter || p->row_end > p->height || p->row_begin >= p->row_end)
@@ -210,7 +247,12 @@ int mandelbrot_launch(mc_context* ctx, const mc_mandelbrot_params* p, void* d_rg
         int rc = ensure_lut(ctx, p, s);
         if (rc) return rc;
     }
+    {
+        int rc = ensure_c_table(ctx, p, s);
+        if (rc) return rc;
+    }
     MandelArgs a;
+    a.c_tab = (const float*)ctx->ctab.ptr;
     a.W = p->width; a.H = p->height; a.max_iter = p->max_iter;
     a.row_begin = p->row_begin; a.row_end = p->row_end;
     a.row_block = p->row_stride ? p->row_block : 0u; a.row_stride = p->row_stride;

@@ -40,6 +40,9 @@ struct mc_context {
     mc::DeviceBuffer lut;
     uint32_t lut_max_iter = 0xffffffffu;
     float lut_kcolor[4] = {0, 0, 0, 0};
+    // per-column / per-row c tables (Mandelbrot), keyed by (W, H, precision, view)
+    mc::DeviceBuffer ctab;
+    std::vector<float> ctab_key;
     // scratch for the host-buffer entry points
     mc::DeviceBuffer scratch_rgba, scratch_iters, scratch_u8;
     // generic path-tracer scenes: device copy of [records | emissive indices] and the host copy it mirrors
