@@ -11,7 +11,7 @@ import re
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmc_compute.so")
+LIB_PATH = os.environ.get("MC_LIB_PATH") or os.path.join(_HERE, "lib", "libmc_compute.so")   # MC_LIB_PATH: diagnostic builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mc_compute.h")
 
 MC_OK = 0

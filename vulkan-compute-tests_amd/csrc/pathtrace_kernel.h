@@ -106,6 +106,23 @@ __device__ __forceinline__ v3 rand01(uint32_t x, uint32_t y, uint32_t z) {
     return v3{(float)x * s, (float)y * s, (float)z * s};
 }
 
+// Diagnostic build only (make stats -> lib/libmc_compute_stats.so, tools/pt_region_stats.py): how often each code
+// region is executed by a wave and with how many active lanes — the divergence picture behind DESIGN.md §3.3.
+#ifdef MC_PT_REGION_STATS
+static __device__ unsigned long long g_region_exec[16];
+static __device__ unsigned long long g_region_lanes[16];
+#define MC_REGION(r)                                                                            \
+    do {                                                                                        \
+        unsigned long long m_ = __ballot(1);                                                    \
+        if ((int)__lane_id() == __ffsll((long long)m_) - 1) {                                   \
+            atomicAdd(&g_region_exec[r], 1ull);                                                 \
+            atomicAdd(&g_region_lanes[r], (unsigned long long)__popcll(m_));                    \
+        }                                                                                       \
+    } while (0)
+#else
+#define MC_REGION(r) do { } while (0)
+#endif
+
 constexpr float kEps = 1e-4f, kTriEps = 1e-7f, kInf = 1e20f;   // pathTracer.comp:103-105
 constexpr float kPi = 3.141592653589793f;                       // :102
 
@@ -261,10 +278,13 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
     v3 ro = a.lc, rd = normalize<Fast>(a.lc - spos);                      // :362
     float emissive = 1.0f;                                                // :365
 
+    MC_REGION(0);   // ray generation done
     for (uint32_t depth = 0; depth < a.max_depth; depth++) {              // :367
+        MC_REGION(1);   // primary intersect
         float t;
         int id = intersect<Fast, NP, NS, Slab, Prec>(sc, uobj, ro, rd, t);
         if (id < 0) break;   // :369 `continue` with an unchanged ray misses again at every later depth: no effect
+        MC_REGION(2);   // bounce prologue
         v3 x = ro + rd * t;                                               // :374 (o + t*d: fp32 mul is commutative)
         const float* obj = lds_obj + 12 * id;                             // per-lane fetch from LDS
         const bool is_sphere = id >= np;
@@ -283,6 +303,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             accmat = divs<Fast>(accmat, p);                               // :397
         }
         if (mat == 1) {                                                   // :400 diffuse
+            MC_REGION(3);   // diffuse: NEE set-up + shadow ray
             const int n_lights = LdsScene ? (int)sc.n_emissive : ns;
             for (int k = 0; k < n_lights; k++) {                          // :403
                 int i = k;
@@ -305,10 +326,12 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 float tne;
                 int idne = intersect<Fast, NP, NS, Slab, Prec>(sc, uobj, x, l, tne);  // :420 shadow ray
                 if (idne == np + i) {
+                    MC_REGION(4);   // shadow ray reached the light
                     float omega = (2.0f * kPi) * (1.0f - cos_a_max);      // :421
                     accrad = accrad + ((divs<Fast>(accmat, kPi) * dm::gmax(dot(l, nl), 0.0f)) * le) * omega;   // :422
                 }
             }
+            MC_REGION(8);   // diffuse bounce direction
             float r1 = (2.0f * kPi) * rnd.x, r2 = rnd.y, r2s = dm::fsqrt<Fast>(r2);   // :426
             v3 w = nl;
             v3 u = normalize<Fast>(cross((__builtin_fabsf(w.x) > 0.1f ? v3{0, 1, 0} : v3{1, 0, 0}), w));   // :427
@@ -319,10 +342,12 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             ro = x;
             emissive = 0.0f;                                              // :429
         } else if (mat == 2) {                                            // :432 mirror
+            MC_REGION(5);   // mirror
             rd = reflect(rd, n);
             ro = x;
             emissive = 1.0f;
         } else if (mat == 3) {                                            // :437 glass
+            MC_REGION(6);   // glass
             bool into = (n.x == nl.x) && (n.y == nl.y) && (n.z == nl.z);  // :438
             const float nc = 1.0f, nt = 1.5f;
             float nnt = into ? dm::fdiv<Fast>(nc, nt) : dm::fdiv<Fast>(nt, nc);   // :439
@@ -330,6 +355,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             float cos2t = 1.0f - (nnt * nnt) * (1.0f - ddn * ddn);        // :440
             v3 refl = reflect(rd, n);
             if (cos2t >= 0.0f) {
+                MC_REGION(7);   // glass: refraction branch
                 float k = (into ? 1.0f : -1.0f) * (ddn * nnt + dm::fsqrt<Fast>(cos2t));
                 v3 tdir = normalize<Fast>(rd * nnt - n * k);              // :441
                 float aa = nt - nc, bb = nt + nc;
