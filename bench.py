@@ -81,6 +81,9 @@ def parse():
     ap.add_argument("--spp", type=int, default=None, help="override spp (diagnostics only; invalidates the headline)")
     ap.add_argument("--width", type=int, default=None, help="override image width (diagnostics only)")
     ap.add_argument("--height", type=int, default=None, help="override per-GPU image height (diagnostics only)")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed region, rank 0 re-renders the whole image on its own GPU and checks that the "
+                         "gathered N-rank image is bit-identical (multi-GPU == single-GPU invariant, SURVEY §8e)")
     return ap.parse_args()
 
 
@@ -105,11 +108,19 @@ def main():
         n = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
+    # MC_BENCH_BACKEND=gloo is a REHEARSAL mode for boxes with fewer GPUs than ranks: the ranks share the visible
+    # devices and the gather is staged through host memory (RCCL refuses two ranks on one GPU).  It exercises the
+    # same sharding / gather / re-assembly code; its timings are meaningless and are labelled as such.
+    backend = os.environ.get("MC_BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(device_index)
     if n > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=n, device_id=torch.device("cuda", local_rank))
-    ctx = B.Context(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=n, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=n)
+    ctx = B.Context(device_index)
     dev_name, cus, _ = ctx.device_info()
     # a non-default torch stream: its handle is non-zero, so the C ABI launches on exactly this stream and the
     # torch.cuda.Event pairs below bracket the kernel (a NULL handle would select the context's own stream)
@@ -199,6 +210,22 @@ def main():
             units_per_step = local_units
     value = units_per_step * args.steps / dt
 
+    # ---- optional self-check: N-rank image == single-GPU image, bit for bit (outside the timed region) ----------
+    verified = None
+    if args.verify and n > 1 and rank == 0:
+        import copy
+        q = copy.copy(p)
+        q.row_begin, q.row_end, q.row_block, q.row_stride = 0, H, 0, 0
+        single = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        if wl == "pathtrace":
+            ctx.pathtrace_device(q, single.data_ptr(), stream=stream)
+        else:
+            ctx.mandelbrot_device(q, single.data_ptr(), 0, stream=stream)
+        torch.cuda.synchronize()
+        verified = bool(torch.equal(single.view(torch.int32), full.view(torch.int32)))
+        if not verified:
+            sys.exit("bench.py --verify: the gathered multi-rank image differs from the single-GPU render")
+
     out = None
     if rank == 0:
         achieved_tflops = local_units * flops_per_unit / (kernel_ms * 1e-3) / 1e12
@@ -210,7 +237,10 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_name, "image": [W, H], "rows_per_gpu": rows_local,
                        "tiling": "whole image" if n == 1 else f"interleaved {ROW_BLOCK}-row blocks, RCCL gather to rank 0",
-                       "device": dev_name, "compute_units": cus},
+                       "device": dev_name, "compute_units": cus,
+                       **({"rehearsal": "MC_BENCH_BACKEND=gloo: ranks share GPUs, gather staged through the host; "
+                                        "timings are NOT a measurement"} if backend != "nccl" and n > 1 else {}),
+                       **({"verified_equal_to_single_gpu": verified} if verified is not None else {})},
             "roofline": {"bound": "valu", "kernel": kern, "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_TFLOPS,
                          "traffic": profiled_traffic(wl, args, n),

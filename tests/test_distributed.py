@@ -89,7 +89,8 @@ def test_sharding_helpers(B):
             assert owned == list(range(H))
             assert S.padded_tile_rows(H, n) == max(len(S.rank_rows(H, r, n)) for r in range(n))
     p = S.shard(B.mandelbrot_params(100, 600), 3, 8)
-    assert (p.row_begin, p.row_end, p.row_block, p.row_stride) == (48, 600, 16, 128)
+    assert (p.row_begin, p.row_end, p.row_block, p.row_stride) == (3 * S.ROW_BLOCK, 600, S.ROW_BLOCK, 8 * S.ROW_BLOCK)
+    assert all(len(S.rank_rows(600 * n, r, n)) == 600 for n in (1, 2, 4, 8) for r in range(n))   # bench weak scaling: equal tiles
     p = S.shard(B.mandelbrot_params(100, 600), 0, 1)
     assert (p.row_begin, p.row_end, p.row_block, p.row_stride) == (0, 600, 0, 0)
     with pytest.raises(RuntimeError):

@@ -10,7 +10,8 @@ Samples are never split across ranks: the fp32 accumulation order is part of the
 import torch
 import torch.distributed as dist
 
-ROW_BLOCK = 16   # = the kernels' largest thread-block tile height, so block boundaries never cut a wave tile
+ROW_BLOCK = 8    # 600*N rows (bench weak scaling) split into exactly 75 blocks per rank; any block height is legal
+                 # (tile-local rows are mapped to storage rows one by one), 8 keeps a wave's 8x8 / 4x4 / 2x2 tile whole
 
 
 def shard(p, rank, n, block=ROW_BLOCK):
@@ -36,6 +37,12 @@ def gather_tiles(tile, rank, n, dst=0):
     """Gathers the equal-sized tiles to `dst`; returns an (n, *tile.shape) tensor there, None elsewhere."""
     if n == 1:
         return tile.unsqueeze(0)
+    if tile.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal mode (several ranks sharing one GPU, no RCCL): stage through host memory
+        host = tile.cpu()
+        bufs = [torch.empty_like(host) for _ in range(n)] if rank == dst else None
+        dist.gather(host, bufs, dst=dst)
+        return torch.stack(bufs).to(tile.device) if rank == dst else None
     bufs = [torch.empty_like(tile) for _ in range(n)] if rank == dst else None
     dist.gather(tile, bufs, dst=dst)
     return torch.stack(bufs) if rank == dst else None
