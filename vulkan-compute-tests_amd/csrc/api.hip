@@ -372,19 +372,21 @@ static int run_test(mc_context* ctx, const void* in_a, size_t bytes_a, const voi
                     size_t bytes_out, void (*launch)(void*, void*, void*, size_t, hipStream_t, int, int), size_t n, int p0,
                     int p1) {
     MC_HIP_TRY(hipSetDevice(ctx->device));
-    void *da = nullptr, *db = nullptr, *dout = nullptr;
-    MC_HIP_TRY(hipMalloc(&da, bytes_a));
-    if (bytes_b) MC_HIP_TRY(hipMalloc(&db, bytes_b));
-    MC_HIP_TRY(hipMalloc(&dout, bytes_out));
-    MC_HIP_TRY(hipMemcpy(da, in_a, bytes_a, hipMemcpyHostToDevice));
-    if (bytes_b) MC_HIP_TRY(hipMemcpy(db, in_b, bytes_b, hipMemcpyHostToDevice));
-    launch(da, db, dout, n, ctx->stream, p0, p1);
+    DeviceBuffer da, db, dout;   // released on every exit path
+    struct Release {
+        DeviceBuffer &a, &b, &c;
+        ~Release() { a.release(); b.release(); c.release(); }
+    } release{da, db, dout};
+    int rc;
+    if ((rc = da.reserve(bytes_a))) return rc;
+    if (bytes_b && (rc = db.reserve(bytes_b))) return rc;
+    if ((rc = dout.reserve(bytes_out))) return rc;
+    MC_HIP_TRY(hipMemcpy(da.ptr, in_a, bytes_a, hipMemcpyHostToDevice));
+    if (bytes_b) MC_HIP_TRY(hipMemcpy(db.ptr, in_b, bytes_b, hipMemcpyHostToDevice));
+    launch(da.ptr, db.ptr, dout.ptr, n, ctx->stream, p0, p1);
     MC_HIP_TRY(hipGetLastError());
     MC_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    MC_HIP_TRY(hipMemcpy(out, dout, bytes_out, hipMemcpyDeviceToHost));
-    (void)hipFree(da);
-    if (db) (void)hipFree(db);
-    (void)hipFree(dout);
+    MC_HIP_TRY(hipMemcpy(out, dout.ptr, bytes_out, hipMemcpyDeviceToHost));
     return MC_OK;
 }
 

@@ -50,6 +50,12 @@ static int gather_and_assemble(mc_multi* m, std::vector<DeviceBuffer>& tiles, De
     if (m->use_rccl) {
         MC_NCCL_TRY(ncclGroupStart());
         for (int i = 0; i < m->n; i++) {
+            // one thread drives all devices: make rank i's device current for its call inside the group
+            if (hipSetDevice(m->ctx[i]->device) != hipSuccess) {
+                (void)ncclGroupEnd();
+                set_error_detail("hipSetDevice failed inside the gather group");
+                return MC_ERR_HIP;
+            }
             // ncclGather is an RCCL extension (rccl.h); bytes are moved as ncclUint8 so vec4 and u32 tiles share the path
             ncclResult_t r = ncclGather(tiles[i].ptr, i == 0 ? gathered.ptr : nullptr, tile_bytes, ncclUint8, 0, m->comms[i],
                                         m->ctx[i]->stream);
