@@ -135,7 +135,8 @@ def main():
         W, Hbase, spp = args.width or K2["W"], args.height or K2["H"], args.spp or K2["spp"]
         H = Hbase * n
         math_mode = B.PT_MATH_FAST if args.math == "fast" else B.PT_MATH_STRICT
-        p = S.shard(B.pathtrace_params(W, H, spp, math_mode=math_mode), rank, n)
+        pt_flags = int(os.environ.get("MC_PT_FLAGS", "0"), 0)    # experiments only (e.g. 2 = MC_PT_KERNEL_PQ)
+        p = S.shard(B.pathtrace_params(W, H, spp, math_mode=math_mode, flags=pt_flags), rank, n)
         units_per_step = W * H * spp                         # samples
         flops_per_unit = FLOPS_PER_SAMPLE_PT
         metric, unit = "path-traced samples/s", "samples/s"

@@ -104,7 +104,8 @@ enum {
 
 /* mc_pathtrace_params.flags — diagnostics; every combination produces bit-identical buffers */
 enum {
-    MC_PT_GENERIC_KERNEL = 1u << 0 /* never use the axis-aligned-slab specialisation of the plane test */
+    MC_PT_GENERIC_KERNEL = 1u << 0, /* never use the axis-aligned-slab specialisation of the plane test */
+    MC_PT_KERNEL_PQ = 1u << 1       /* two-path-slots-per-lane scheduler (csrc/pathtrace_pq.h) for slab scenes */
 };
 #define MC_PT_FORCE_S(s) ((uint32_t)(s) << 8) /* force the sample-parallel width: 1, 4 or 16 (0 = automatic) */
 /* Sphere-test precision branch of pathTracer.comp:132-256.  The reference compiles every variant OUT

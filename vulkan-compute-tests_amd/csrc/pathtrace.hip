@@ -1,6 +1,8 @@
 // Host side of the path tracer launch: argument validation, camera basis, scene analysis (slab
 // specialisation, emissive mask), choice of the sample-parallel width S.  Device code: pathtrace_kernel.h.
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "pathtrace_kernel.h"
@@ -127,8 +129,16 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
     if (S == 0) S = choose_S((uint64_t)rows * p->width, p->sample_end - p->sample_begin);
     if (S != 1 && S != 4 && S != 16) return MC_ERR_INVALID_ARGUMENT;
     if (prec != 0 && S == 4) S = (p->sample_end - p->sample_begin) >= 16 ? 16 : 1;   // precision variants exist for S = 1, 16
-    int rc = p->math_mode == MC_PT_MATH_FAST ? pt::launch_fast(a, slab ? 1 : 0, S, prec, rows, s)
-                                             : pt::launch_strict(a, slab ? 1 : 0, S, prec, rows, s);
+    int variant = slab ? 1 : 0;
+    // two-path-slots-per-lane scheduler (pathtrace_pq.h): slab scenes, depth fits its 4-bit field
+    if (slab && (p->flags & MC_PT_KERNEL_PQ) && p->max_depth <= 15u) variant = 2;
+    a.pq_regen_threshold = 24u; a.pq_spec_threshold = 16u;
+    if (const char* e = std::getenv("MC_PT_PQ_THRESHOLDS")) {   // experiments: "regen,spec"
+        unsigned r = 0, sp = 0;
+        if (std::sscanf(e, "%u,%u", &r, &sp) == 2 && r >= 1 && r <= 64 && sp >= 1 && sp <= 64) { a.pq_regen_threshold = r; a.pq_spec_threshold = sp; }
+    }
+    int rc = p->math_mode == MC_PT_MATH_FAST ? pt::launch_fast(a, variant, S, prec, rows, s)
+                                             : pt::launch_strict(a, variant, S, prec, rows, s);
     if (rc) return rc;
     MC_HIP_TRY(hipGetLastError());
     return MC_OK;

@@ -1,10 +1,15 @@
 // Instantiates the MC_PT_MATH_FAST path tracer kernels (gfx950 hardware rcp/rsq/sqrt/sin/cos/exp/log).
 // Split from the strict instantiations so the two halves compile in parallel.
 #include "pathtrace_kernel.h"
+#include "pathtrace_pq.h"
 
 namespace mc {
 namespace pt {
 int launch_fast(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s) {
+    if (variant == 2) {   // two-path-slots-per-lane scheduler (pathtrace_pq.h), slab scenes only
+        launch_pq<true>(a, tile_rows, s);
+        return MC_OK;
+    }
     return launch_impl<true>(a, variant, S, prec, tile_rows, s);
 }
 }  // namespace pt

@@ -68,6 +68,7 @@ struct SceneArgs {
 
 struct PTArgs {
     uint32_t W, H, spp, sample_begin, sample_end, max_depth, row_begin, row_end, row_block, row_stride;
+    uint32_t pq_regen_threshold, pq_spec_threshold;   // pathtrace_pq.h scheduler thresholds (lanes)
     // camera basis (pathTracer.comp:352-353,360), evaluated once on the host with the same IEEE ops
     v3 cam_o, cam_d, cx, cy, lc;
     float4* __restrict__ out;   // tile-local storage rows
