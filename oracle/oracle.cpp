@@ -158,6 +158,9 @@ void oracle_ds_op(int op, uint64_t n, const float* a, const float* b, float* out
             case 6: r = df64_mult(x, y); break;
             case 7: r = df64_sqrt(x); break;
             case 8: r = ds_twoProd(x.x, y.x); break;
+            case 9: r = ds_div(x, y); break;
+            case 10: r = twoDiff(x.x, y.x); break;
+            case 11: r = ds2{df64_eq(x, y) ? 1.0f : 0.0f, df64_neq(x, y) ? 1.0f : 0.0f}; break;
             default: r = ds2{ds_compare(x, y), 0.0f}; break;
         }
         out[2 * i] = r.x; out[2 * i + 1] = r.y;

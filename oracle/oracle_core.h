@@ -295,6 +295,42 @@ inline ds2 ds_dot3(ds2 ax, ds2 ay, ds2 az, ds2 bx, ds2 by, ds2 bz) {       // :2
     return ds_add(ds_add(ds_mul(ax, bx), ds_mul(ay, by)), ds_mul(az, bz));
 }
 
+// ds_div — emulateDouble.h.glsl:143-178 (hand-typed in the reference, "may contain typos", :142; restated as written)
+inline ds2 ds_div(ds2 a, ds2 b) {
+    const float split = 8193.0f;
+    float s1 = a.x / b.x;
+    float cona = s1 * split;
+    float conb = b.x * split;
+    float a1 = cona - (cona - s1);
+    float b1 = conb - (conb - b.x);
+    float a2 = s1 - a1;
+    float b2 = b.x - b1;
+    float c11 = s1 * b.x;
+    float c21 = (((a1 * b1 - c11) + a1 * b2) + a2 * b1) + a2 * b2;
+    float c2 = s1 * b.y;
+    float t1 = c11 + c2;
+    float e = t1 - c11;
+    float t2 = ((c2 - e) + (c11 - (t1 - e))) + c21;
+    float t12 = t1 + t2;
+    float t22 = t2 - (t12 - t1);
+    float t11 = a.x - t12;
+    e = t11 - a.x;
+    float t21 = ((-t12 - e) + (a.x - (t11 - e))) + a.y - t22;
+    float s2 = (t11 + t21) / b.x;
+    ds2 c;
+    c.x = s1 + s2;
+    c.y = s2 - (c.x - s1);
+    return c;
+}
+inline ds2 twoDiff(float a, float b) {                                     // :272-277
+    float s = a - b;
+    float v = s - a;
+    float e = (a - (s - v)) - (b + v);
+    return ds2{s, e};
+}
+inline bool df64_eq(ds2 a, ds2 b) { return a.x == b.x && a.y == b.y; }     // :243-246
+inline bool df64_neq(ds2 a, ds2 b) { return a.x != b.x || a.y != b.y; }    // :248-251
+
 // ---- DF64_F32_F32 package — emulateDouble.h.glsl:225-356 (A. Thall's df64) ---------------------------------
 inline ds2 df64_from_f32(float v) { return ds2{v, 0.0f}; }                 // :232-235
 inline bool df64_lt(ds2 a, ds2 b) { return a.x < b.x || (a.x == b.x && a.y < b.y); }   // :253-255

@@ -177,7 +177,7 @@ def rand01(xyz):
 
 
 DS_OPS = {"add": 0, "sub": 1, "mul": 2, "compare": 3, "sqrt": 4, "df64_add": 5, "df64_mult": 6, "df64_sqrt": 7,
-          "twoprod": 8}
+          "twoprod": 8, "div": 9, "twodiff": 10, "df64_eqneq": 11}
 
 
 def ds_op(op, a, b):

@@ -400,7 +400,7 @@ def test_k2_render_reproduces_the_reference_image_per_pixel(ctx, B):
 # the reference's actual use of emulated double — extended-precision sphere tests
 # (pathTracer.comp:132-256) with the TEST_PRECISION_WITH_LARGE_SPHERE_WALLS scene (pathtracerApp.h:28-38)
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("op", ["sqrt", "df64_add", "df64_mult", "df64_sqrt", "twoprod"])
+@pytest.mark.parametrize("op", ["sqrt", "df64_add", "df64_mult", "df64_sqrt", "twoprod", "div", "twodiff", "df64_eqneq"])
 def test_df64_and_ds_sqrt_primitives_bit_exact(ctx, O, op):
     rng = np.random.default_rng(11)
     n = 20000

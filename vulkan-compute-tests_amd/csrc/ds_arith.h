@@ -114,6 +114,43 @@ __device__ __forceinline__ ds2 ds_dot3(ds2 ax, ds2 ay, ds2 az, ds2 bx, ds2 by, d
     return ds_add(ds_add(ds_mul(ax, bx), ds_mul(ay, by)), ds_mul(az, bz));
 }
 
+// ds_div — emulateDouble.h.glsl:143-178.  Not used by any shader path (the reference notes it was hand-typed and may
+// contain typos, :142); restated as written so the DS package is complete.  Both divisions are IEEE.
+__device__ __forceinline__ ds2 ds_div(ds2 a, ds2 b) {
+    const float split = 8193.0f;
+    float s1 = a.hi / b.hi;
+    float cona = s1 * split;
+    float conb = b.hi * split;
+    float a1 = cona - (cona - s1);
+    float b1 = conb - (conb - b.hi);
+    float a2 = s1 - a1;
+    float b2 = b.hi - b1;
+    float c11 = s1 * b.hi;
+    float c21 = (((a1 * b1 - c11) + a1 * b2) + a2 * b1) + a2 * b2;
+    float c2 = s1 * b.lo;
+    float t1 = c11 + c2;
+    float e = t1 - c11;
+    float t2 = ((c2 - e) + (c11 - (t1 - e))) + c21;
+    float t12 = t1 + t2;
+    float t22 = t2 - (t12 - t1);
+    float t11 = a.hi - t12;
+    e = t11 - a.hi;
+    float t21 = ((-t12 - e) + (a.hi - (t11 - e))) + a.lo - t22;
+    float s2 = (t11 + t21) / b.hi;
+    ds2 c;
+    c.hi = s1 + s2;
+    c.lo = s2 - (c.hi - s1);
+    return c;
+}
+__device__ __forceinline__ ds2 twoDiff(float a, float b) {                 // :272-277
+    float s = a - b;
+    float v = s - a;
+    float e = (a - (s - v)) - (b + v);
+    return ds2{s, e};
+}
+__device__ __forceinline__ bool df64_eq(ds2 a, ds2 b) { return a.hi == b.hi && a.lo == b.lo; }    // :243-246
+__device__ __forceinline__ bool df64_neq(ds2 a, ds2 b) { return a.hi != b.hi || a.lo != b.lo; }   // :248-251
+
 // ---- DF64_F32_F32 package — emulateDouble.h.glsl:225-356 (pathTracer.comp:214-256) --------------------------
 __device__ __forceinline__ ds2 df64_from_f32(float v) { return ds2{v, 0.0f}; }                     // :232-235
 __device__ __forceinline__ bool df64_lt(ds2 a, ds2 b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }   // :253-255
