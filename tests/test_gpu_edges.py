@@ -1,0 +1,64 @@
+"""GPU parity edge cases for the path tracer: degenerate image sizes, depth limits other than 12, one-row tiles,
+a scene without any light, a scene whose only object is missed by most rays (the `continue` on a miss,
+pathTracer.comp:369).  Strict math, bit-identical to the oracle, every kernel variant."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+VARIANTS = [("S1", lambda B: B.pt_force_s(1)), ("S4", lambda B: B.pt_force_s(4)), ("S16", lambda B: B.pt_force_s(16)),
+            ("generic", lambda B: B.PT_GENERIC_KERNEL), ("pq", lambda B: B.PT_KERNEL_PQ)]
+
+
+@pytest.mark.parametrize("W,H,spp", [(1, 1, 3), (2, 1, 17), (1, 7, 5), (3, 2, 1)])
+def test_degenerate_image_sizes(ctx, B, O, W, H, spp):
+    ref = O.pathtrace(W, H, spp, math_mode=O.MATH_MC)
+    for name, fl in VARIANTS:
+        out = ctx.pathtrace(B.pathtrace_params(W, H, spp, flags=fl(B)))
+        assert np.array_equal(bits(out), bits(ref)), name
+
+
+@pytest.mark.parametrize("max_depth", [1, 2, 6, 7, 15])
+def test_depth_limits(ctx, B, O, max_depth):
+    W, H, spp = 24, 16, 6
+    ref = O.pathtrace(W, H, spp, math_mode=O.MATH_MC, max_depth=max_depth)
+    for name, fl in VARIANTS:
+        out = ctx.pathtrace(B.pathtrace_params(W, H, spp, max_depth=max_depth, flags=fl(B)))
+        assert np.array_equal(bits(out), bits(ref)), (name, max_depth)
+
+
+def test_depth_beyond_the_pq_field_falls_back(ctx, B, O):
+    """max_depth 20 does not fit the two-slot scheduler's 4-bit depth field: the launch must fall back, not fail."""
+    ref = O.pathtrace(16, 12, 3, math_mode=O.MATH_MC, max_depth=20)
+    out = ctx.pathtrace(B.pathtrace_params(16, 12, 3, max_depth=20, flags=B.PT_KERNEL_PQ))
+    assert np.array_equal(bits(out), bits(ref))
+
+
+def test_one_row_tiles_and_last_row(ctx, B, O):
+    W, H, spp = 33, 9, 4
+    whole = O.pathtrace(W, H, spp, math_mode=O.MATH_MC)
+    for r in (0, 4, 8):
+        for name, fl in VARIANTS:
+            t = ctx.pathtrace(B.pathtrace_params(W, H, spp, row_begin=r, row_end=r + 1, flags=fl(B)))
+            assert np.array_equal(bits(t), bits(whole[r:r + 1])), (r, name)
+
+
+def test_scene_without_lights_and_with_misses(ctx, B, O):
+    # no emissive sphere at all: NEE loop skips everything, image is black (0.5 after the +0.5 bias)
+    planes, spheres = O.DEFAULT_PLANES.copy(), O.DEFAULT_SPHERES.copy().reshape(3, 12)
+    spheres[2, 4:7] = 0
+    out = ctx.pathtrace(B.pathtrace_params(20, 12, 3), planes=planes, spheres=spheres)
+    ref = O.pathtrace(20, 12, 3, planes=planes, spheres=spheres, math_mode=O.MATH_MC)
+    assert np.array_equal(bits(out), bits(ref)) and np.all(ref[..., :3] == 0.5)
+    # open scene: one floor plane + the light; most rays miss everything
+    floor = O.DEFAULT_PLANES.reshape(6, 12)[3:4].copy()
+    light = O.DEFAULT_SPHERES.reshape(3, 12)[2:3].copy()
+    out = ctx.pathtrace(B.pathtrace_params(32, 20, 8), planes=floor, spheres=light)
+    ref = O.pathtrace(32, 20, 8, planes=floor, spheres=light, math_mode=O.MATH_MC)
+    assert np.array_equal(bits(out), bits(ref))
+    assert len(np.unique(ref[..., 0])) > 3
