@@ -279,6 +279,21 @@ def main():
                             "workload": f"mandelbrot {K1['W']}x{K1['H']} M{K1['M']} fp32", "pixel_iters": pi, "kernel_ms": ms,
                             "roofline": {"bound": "valu", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                                          "frac": tf / PEAK_FP32_TFLOPS, "lane_ops_frac": tf * 1e12 / PEAK_LANE_OPS}}
+        if args.math == "fast" and not (args.width or args.height or args.spp):
+            # the same workload with MC_PT_MATH_STRICT (IEEE divide/sqrt + mc_math: bit-identical to the oracle)
+            ps = B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_STRICT)
+            ctx.pathtrace_device(ps, tile.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            reps = 5
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                ctx.pathtrace_device(ps, tile.data_ptr(), stream=stream)
+            e1.record()
+            torch.cuda.synchronize()
+            sms = e0.elapsed_time(e1) / reps
+            out["strict_math"] = {"metric": metric, "value": W * H * spp / (sms * 1e-3), "unit": unit, "kernel_ms": sms,
+                                  "note": "bit-identical to the CPU oracle (tests/test_gpu_parity.py)"}
 
     if rank == 0 and n == 1 and not args.no_cpu_baseline:
         O = entry.load_oracle()   # TEST INFRASTRUCTURE, used here only as the timed CPU baseline
