@@ -197,7 +197,8 @@ int mc_test_math(mc_context* ctx, int fn, int fast, const float* in, float* out,
 /* rand01 (pathTracer.comp:107-110) over n keys (x,y,z) -> 3 floats each. */
 int mc_test_rand01(mc_context* ctx, const uint32_t* xyz, float* out, size_t n);
 /* two-float primitives (emulateDouble.h.glsl): op 0 ds_add, 1 ds_sub, 2 ds_mul, 3 ds_compare, 4 ds_sqrt(a), 5 df64_add,
- * 6 df64_mult, 7 df64_sqrt(a), 8 ds_twoProd(a.hi,b.hi), 9 ds_div, 10 twoDiff(a.hi,b.hi), 11 (df64_eq, df64_neq) as 0/1;
+ * 6 df64_mult, 7 df64_sqrt(a), 8 ds_twoProd(a.hi,b.hi), 9 ds_div, 10 twoDiff(a.hi,b.hi), 11 (df64_eq, df64_neq) as 0/1,
+ * 12 ds_mul with the one-fma error term (the two-float Mandelbrot's fast block; equals op 2 for |hi| in [2^-50, 2^60));
  * n pairs of (hi,lo). */
 int mc_test_ds_op(mc_context* ctx, int op, const float* a, const float* b, float* out, size_t n);
 

@@ -36,6 +36,33 @@ def test_ds_ops_bit_exact(ctx, O, op):
     assert np.array_equal(bits(ctx.test_ds_op(op, a, b)), bits(O.ds_op(op, a, b)))
 
 
+def test_ds_mul_fma_equals_the_dekker_product_inside_its_precondition(ctx, O):
+    """The two-float Mandelbrot's fast block replaces Dekker's 16-operation error term by one fma (ds_arith.h,
+    tools/dekker_vs_fma.c).  On the device: identical to the ORACLE's literal ds_mul for |hi| in [2^-50, 2^60),
+    up to the sign of a zero low word; squares included (b == a)."""
+    rng = np.random.default_rng(12)
+    n = 400000
+    def operand(e_lo=-50, e_hi=60):
+        mant = rng.integers(0, 1 << 23, n, dtype=np.uint32)
+        mant[: n // 8] |= rng.choice(np.array([0x7fffff, 0x1fff, 0x0fff, 0x1000, 0x7ff000], np.uint32), n // 8)
+        e = rng.integers(e_lo, e_hi, n).astype(np.int64)
+        sign = rng.integers(0, 2, n).astype(np.uint32) << 31
+        hi = (sign | ((e + 127).astype(np.uint32) << 23) | mant).view(np.float32)
+        lo = (hi.astype(np.float64) * rng.uniform(-1, 1, n) * 2.0 ** -24).astype(np.float32)
+        return np.stack([hi, lo], 1)
+    a, b = operand(), operand()
+    b[: n // 4] = a[: n // 4]
+    keep = np.abs(a[:, 0].astype(np.float64) * b[:, 0]) < 2.0 ** 100
+    a, b = a[keep], b[keep]
+    got, ref = ctx.test_ds_op("mul_fma", a, b), O.ds_op("mul", a, b)
+    same = (bits(got) == bits(ref)) | ((got == 0) & (ref == 0))
+    assert same.all(), int((~same).sum())
+    # negative control: far below the precondition the two forms do differ (this is why the kernel tracks it)
+    t, u = operand(-62, -56), operand(-62, -56)
+    got, ref = ctx.test_ds_op("mul_fma", t, u), O.ds_op("mul", t, u)
+    assert (bits(got) != bits(ref)).any()
+
+
 @pytest.mark.parametrize("fn,lo,hi", [("sin", 0.0, 6.2831855), ("cos", 0.0, 6.2831855), ("sin", -50.0, 50.0),
                                       ("cos", -50.0, 50.0), ("log2", 0.0, 1.0), ("exp2", -130.0, 0.0),
                                       ("pow045", 0.0, 1.0)])
@@ -121,7 +148,12 @@ def test_mandelbrot_row_tiles_equal_whole(ctx, B, O):
 
 @pytest.mark.parametrize("centre,scale,M,W,H", [((-0.7436438870371587, 0.13182590420531198), (1e-8, 1e-8 * 2 / 3), 2000, 96, 64),
                                                 ((-0.445, 0.0), (2.34, 2.34), 200, 128, 128),
-                                                ((-0.743643887037151, 0.131825904205330), (3e-5, 2e-5), 1500, 50, 37)])
+                                                ((-0.743643887037151, 0.131825904205330), (3e-5, 2e-5), 1500, 50, 37),
+                                                # c ~ i (Misiurewicz point): zx passes through |zx| < 2^-50 every other
+                                                # iteration -> the fma fast block must hand over to the literal Dekker
+                                                # product; row y == 0 of the default view does the same via exact zeros
+                                                ((0.0, 1.0), (1e-15, 1e-15), 600, 64, 48),
+                                                ((0.0, 1.0), (3e-14, 2e-14), 600, 64, 48)])
 def test_mandelbrot_ds_iteration_plane(ctx, B, O, centre, scale, M, W, H):
     p = B.mandelbrot_params(W, H, max_iter=M, precision=B.PRECISION_DS, centre=centre, scale=scale)
     _, iters = ctx.mandelbrot(p, want_rgba=False)

@@ -108,6 +108,7 @@ __global__ void test_ds_kernel(int op, const float* __restrict__ a, const float*
         case 9: r = ds_div(x, y); break;
         case 10: r = twoDiff(x.hi, y.hi); break;
         case 11: r = ds2{df64_eq(x, y) ? 1.0f : 0.0f, df64_neq(x, y) ? 1.0f : 0.0f}; break;
+        case 12: r = ds_mul_fma(x, y); break;
         default: r = ds2{ds_compare(x, y), 0.0f}; break;
     }
     out[2 * i] = r.hi; out[2 * i + 1] = r.lo;

@@ -81,6 +81,26 @@ __host__ __device__ __forceinline__ ds2 ds_mul(ds2 a, ds2 b) {                  
     return c;
 }
 
+// ds_mul with the Dekker error term c21 (8 splitting + 8 product/sum operations) replaced by one fma.  Dekker's sequence
+// is an error-free transformation: with split 2^13+1 the four partial products and every partial sum are exact in
+// fp32, so c21 == a.hi*b.hi - fl(a.hi*b.hi) == fmaf(a.hi, b.hi, -c11) bit for bit (up to the sign of an exact zero,
+// which no later operation can turn into a different value) PROVIDED the error term is representable: ulp(a.hi) *
+// ulp(b.hi) >= 2^-149 and no overflow of a.hi*8193.  tools/dekker_vs_fma.c checks 4e8 random + 7e6 adversarial
+// pairs in that range.  The caller owns the precondition (mandelbrot.hip: |operands| >= 2^-50, else the literal
+// ds_mul runs).
+__device__ __forceinline__ ds2 ds_mul_fma(ds2 a, ds2 b) {
+    float c11 = a.hi * b.hi;
+    float c21 = __builtin_fmaf(a.hi, b.hi, -c11);
+    float c2 = a.hi * b.lo + a.lo * b.hi;
+    float t1 = c11 + c2;
+    float e = t1 - c11;
+    float t2 = a.lo * b.lo + ((c2 - e) + (c11 - (t1 - e))) + c21;
+    ds2 c;
+    c.hi = t1 + t2;
+    c.lo = t2 - (c.hi - t1);
+    return c;
+}
+
 // ds_mul(a, a): same operation sequence with b == a (the compiler CSEs the duplicated split).
 __device__ __forceinline__ ds2 ds_sqr(ds2 a) { return ds_mul(a, a); }
 

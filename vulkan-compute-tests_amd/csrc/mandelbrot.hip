@@ -71,9 +71,11 @@ struct StateF32 {
     // > 2.0f has bit 30 set or is 0x40000001..., every value < 2.0f has bit 30 clear, so the bitwise OR of a
     // block's magnitudes exceeds 0x40000000 whenever any of them exceeded 2.0f (no false negatives; the only
     // false positives involve a magnitude of exactly 2.0f).  v_or_b32 issues in 2 cycles, v_cmp_*_f32 in 4.
-    static constexpr bool kHasBitFilter = true;
-    __device__ __forceinline__ uint32_t advance_bits() { return __float_as_uint(advance()); }
-    static __device__ __forceinline__ bool bits_may_have_escaped(uint32_t or_of_bits) { return or_of_bits > 0x40000000u; }
+    static constexpr bool kHasFastBlock = true;
+    using Acc = uint32_t;
+    __device__ __forceinline__ Acc acc_init() const { return 0u; }
+    __device__ __forceinline__ void advance_fast(Acc& acc) { acc |= __float_as_uint(advance()); }
+    static __device__ __forceinline__ bool needs_exact(Acc or_of_bits) { return or_of_bits > 0x40000000u; }
 };
 
 struct StateDS {
@@ -85,9 +87,41 @@ struct StateDS {
         cy = ds2{ty.x, ty.y};
         zx = zy = sx = sy = ds_set(0.0f);
     }
-    static constexpr bool kHasBitFilter = false;   // 142 flops per iteration: the exact compare is noise
-    __device__ __forceinline__ uint32_t advance_bits() { return 0u; }
-    static __device__ __forceinline__ bool bits_may_have_escaped(uint32_t) { return true; }
+    // Fast block: the same iteration with
+    //  (1) the Dekker error term of each product replaced by ONE fma — bit-identical whenever the error term is
+    //      representable (tools/dekker_vs_fma.c; error-free transformation), which holds for |operand| >= 2^-50;
+    //      `mn` tracks the smallest square seen, a block containing a smaller operand (or an exact zero) is redone
+    //      with the literal sequence;
+    //  (2) the 11-flop ds_add + 3-way compare of the escape test replaced by t = sx.hi + sy.hi and an integer
+    //      max: ds_add(sx, sy).hi differs from t by < 4 ulp (|t2| <= 1/2 ulp(t) + |sx.lo| + |sy.lo|), so
+    //      t < 2 - 16 ulp proves "not escaped"; a block that gets closer is redone exactly.
+    // Both substitutions leave the state words of every unfinished lane bit-identical to step()'s.
+    static constexpr bool kHasFastBlock = true;
+    struct Acc {
+        uint32_t mx;   // max over the block of bits(t), unsigned: a negative or NaN t reads as "large"
+        int32_t mn;    // min over the block of bits(square.hi), signed: a negative square reads as "small"
+    };
+    __device__ __forceinline__ Acc acc_init() const {
+        int32_t a = __float_as_int(sx.hi), b = __float_as_int(sy.hi);
+        return Acc{0u, a < b ? a : b};   // the incoming z is an operand of this block's first zx*zy
+    }
+    __device__ __forceinline__ void advance_fast(Acc& acc) {
+        ds2 zxy = ds_mul_fma(zx, zy);
+        ds2 twoxy = ds2{2.0f * zxy.hi, 2.0f * zxy.lo};
+        ds2 nzx = ds_add(ds_sub(sx, sy), cx);
+        ds2 nzy = ds_add(twoxy, cy);
+        zx = nzx; zy = nzy;
+        sx = ds_mul_fma(zx, zx); sy = ds_mul_fma(zy, zy);
+        int32_t bx = __float_as_int(sx.hi), by = __float_as_int(sy.hi);
+        uint32_t bt = __float_as_uint(sx.hi + sy.hi);
+        acc.mx = acc.mx > bt ? acc.mx : bt;
+        int32_t m = bx < by ? bx : by;
+        acc.mn = acc.mn < m ? acc.mn : m;
+    }
+    static __device__ __forceinline__ bool needs_exact(Acc acc) {
+        // 0x3ffffff0 = 2 - 16 ulp; 0x0e800000 = 2^-98 > (2^-50)^2 (sx.hi is within an ulp of zx.hi^2)
+        return acc.mx >= 0x3ffffff0u || acc.mn < 0x0e800000;
+    }
     __device__ __forceinline__ bool step() {
         ds2 zxy = ds_mul(zx, zy);
         ds2 twoxy = ds2{2.0f * zxy.hi, 2.0f * zxy.lo};   // exact
@@ -109,14 +143,15 @@ __device__ __forceinline__ uint32_t escape_time(State& st, uint32_t max_iter, bo
     uint32_t n = max_iter;
     uint32_t i = 0;
     for (; i + U <= max_iter; i += U) {
-        if (State::kHasBitFilter && i != 0) {   // the first block is evaluated exactly: most tiles escape right there
-            // fast path: U iterations of pure add/mul/or, ONE compare per block; the exact per-iteration
-            // ballots below are evaluated (from the saved state) only if some unfinished lane may have escaped
+        if (State::kHasFastBlock && i != 0) {   // the first block is evaluated exactly: most tiles escape right there
+            // fast path: U iterations without per-iteration compares/ballots, ONE test per block; the exact
+            // per-iteration ballots below are evaluated (from the saved state) only if some unfinished lane may
+            // have escaped (or, two-float state, may have left the fast arithmetic's precondition)
             State probe = st;
-            uint32_t acc = 0u;
+            typename State::Acc acc = st.acc_init();
 #pragma unroll
-            for (int k = 0; k < U; k++) acc |= probe.advance_bits();
-            if ((__ballot(State::bits_may_have_escaped(acc)) & ~done) == 0ull) {
+            for (int k = 0; k < U; k++) probe.advance_fast(acc);
+            if ((__ballot(State::needs_exact(acc)) & ~done) == 0ull) {
                 st = probe;
                 continue;
             }
@@ -264,7 +299,7 @@ int mandelbrot_launch(mc_context* ctx, const mc_mandelbrot_params* p, void* d_rg
     const uint32_t rows = tile_rows(p->row_begin, p->row_end, a.row_block, a.row_stride);
     dim3 grid((p->width + 15u) / 16u, (rows + 15u) / 16u), block(256);
     if (p->precision == MC_PRECISION_DS) {
-        hipLaunchKernelGGL((mandelbrot_kernel<StateDS, 2>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((mandelbrot_kernel<StateDS, 4>), grid, block, 0, s, a);
     } else if (p->flags & MC_MANDEL_FMA) {
         hipLaunchKernelGGL((mandelbrot_kernel<StateF32<true>, 8>), grid, block, 0, s, a);
     } else {
