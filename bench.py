@@ -54,7 +54,7 @@ def profiled_traffic(wl, args, n):
         return None
     tag = {"pathtrace": "pt_fast" if args.math == "fast" else "pt_strict", "mandelbrot": "mandel",
            "mandelbrot_ds": "mandel_ds"}[wl]
-    for rnd in ("r01c", "r01b"):
+    for rnd in ("r01d", "r01c", "r01b"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}_pmc_summary.json")
         if os.path.exists(path):
             try:
@@ -256,7 +256,9 @@ def main():
                                       "note": ("142 = the reference composition's literal flop count; the kernel gets the same "
                                                "bits from ~87 issued instructions (Dekker error term = one fma, exact), "
                                                "so this fraction may exceed 1") if wl == "mandelbrot_ds" else
-                                              "parity forbids contraction: one issue slot per flop"}},
+                                              ("fast math: hardware transcendentals and a*b+c contraction (toleranced parity); "
+                                               "the strict kernel, reported beside it, forbids both") if wl == "pathtrace" and args.math == "fast"
+                                              else "parity forbids contraction: one issue slot per flop"}},
         }
 
     # ---- secondary metric + CPU baseline: rank 0, N = 1 only, outside the timed region ------------------

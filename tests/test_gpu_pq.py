@@ -18,11 +18,14 @@ def test_pq_strict_bit_exact(ctx, B, O, W, H, spp):
     assert np.array_equal(bits(out), bits(ref))
 
 
-def test_pq_fast_equals_round_synchronous_fast(ctx, B):
+def test_pq_fast_close_to_round_synchronous_fast(ctx, B):
+    """Fast math allows a*b+c contraction (pathtrace_fast.hip), and the two kernels are different instruction
+    sequences: equal within the fast-math tolerance, not bit for bit (strict math above IS bit for bit)."""
     W, H, spp = 64, 40, 33
     a = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, flags=B.PT_KERNEL_PQ))
     b = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST))
-    assert np.array_equal(bits(a), bits(b))
+    d = (a[..., :3] - b[..., :3]).astype(np.float64)
+    assert np.sqrt((d ** 2).mean()) < 1.0 and abs(d.mean()) < 0.1
 
 
 def test_pq_progressive_ranges_and_tiles(ctx, B, O):

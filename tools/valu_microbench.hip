@@ -99,6 +99,22 @@ KERNELU32(k_mullo, BODY1("v_mul_lo_u32"))
 KERNELU32(k_xor, BODY1("v_xor_b32"))
 KERNELU32(k_lshr, BODY1("v_lshrrev_b32"))
 KERNELU32(k_addu, BODY1("v_add_u32"))
+// second series (round 1, after the fast-math contraction result): the "other" class of the issue model
+#define BODY_CNDMASK                                                                                       \
+    asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n\tv_cndmask_b32 %1, %1, %8, vcc\n\tv_cndmask_b32 %2, %2, %8, vcc\n\t" \
+                 "v_cndmask_b32 %3, %3, %8, vcc\n\tv_cndmask_b32 %4, %4, %8, vcc\n\tv_cndmask_b32 %5, %5, %8, vcc\n\t" \
+                 "v_cndmask_b32 %6, %6, %8, vcc\n\tv_cndmask_b32 %7, %7, %8, vcc\n\tv_cndmask_b32 %0, %0, %8, vcc\n\t" \
+                 "v_cndmask_b32 %1, %1, %8, vcc\n\tv_cndmask_b32 %2, %2, %8, vcc\n\tv_cndmask_b32 %3, %3, %8, vcc\n\t" \
+                 "v_cndmask_b32 %4, %4, %8, vcc\n\tv_cndmask_b32 %5, %5, %8, vcc\n\tv_cndmask_b32 %6, %6, %8, vcc\n\t" \
+                 "v_cndmask_b32 %7, %7, %8, vcc\n\t"                                                                    \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)                         \
+                 : "v"(b)                                                                                                 \
+                 : "vcc")
+KERNELU32(k_mov, BODY_UN("v_mov_b32"))
+KERNELU32(k_cndmask, BODY_CNDMASK)
+KERNELU32(k_and, BODY1("v_and_b32"))
+KERNEL32(k_fmac, BODY1("v_fmac_f32"))
+KERNEL32(k_sub, BODY1("v_sub_f32"))
 
 struct Entry {
     const char* name;
@@ -120,6 +136,8 @@ int main() {
         {"v_rcp_f32", k_rcp, 1},     {"v_rsq_f32", k_rsq, 1},       {"v_sqrt_f32", k_sqrt, 1},   {"v_sin_f32", k_sin, 1},
         {"v_exp_f32", k_exp, 1},     {"v_log_f32", k_log, 1},       {"v_cvt_f32_u32", k_cvt, 0}, {"v_rndne_f32", k_rndne, 0},
         {"v_mul_lo_u32", k_mullo, 0}, {"v_xor_b32", k_xor, 0},      {"v_lshrrev_b32", k_lshr, 0}, {"v_add_u32", k_addu, 0},
+        {"v_mov_b32", k_mov, 0},     {"v_cndmask_b32", k_cndmask, 0}, {"v_and_b32", k_and, 0},   {"v_fmac_f32", k_fmac, 2},
+        {"v_sub_f32", k_sub, 1},
     };
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));

@@ -1,5 +1,18 @@
 // Instantiates the MC_PT_MATH_FAST path tracer kernels (gfx950 hardware rcp/rsq/sqrt/sin/cos/exp/log).
 // Split from the strict instantiations so the two halves compile in parallel.
+//
+// MC_PT_MATH_FAST is the toleranced mode (tests: RMSE <= 0.5 of an 8-bit step against the oracle, statistics of the
+// reference's README image), so this translation unit — and only this one — lets the compiler contract a*b+c into
+// v_fma_f32: measured 32.3 -> 28.0 ms at K2 (profiles/r01_valu_microbench.txt: one v_fma issues in the 4 cycles a
+// v_mul + v_add pair takes, but it is one instruction to fetch, decode and schedule instead of two dependent ones).
+// The two-float / df64 primitives and the explicit-polynomial math are included FIRST, under the command line's
+// -ffp-contract=off: their error-free transformations must never be contracted, in either mode.
+#include <hip/hip_runtime.h>
+
+#include "mc_internal.h"
+#include "ds_arith.h"
+#include "mc_math.h"
+#pragma clang fp contract(fast)   // (reassociate(on) on top of this was tried: 697 vs 700 VALU instructions, not kept)
 #include "pathtrace_kernel.h"
 #include "pathtrace_pq.h"
 
