@@ -84,3 +84,48 @@ def test_scene_change_between_launches(ctx, B, O):
         out = ctx.pathtrace(B.pathtrace_params(20, 12, 3), planes=planes, spheres=spheres)
         ref = O.pathtrace(20, 12, 3, planes=planes, spheres=spheres, math_mode=O.MATH_MC)
         assert np.array_equal(bits(out), bits(ref))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# shadow rays skip the slab tests when the host proves the lights lie inside the closed box (pathtrace.hip,
+# lights_inside_box).  Strict math must stay bit-identical to the oracle (which never skips anything) whether the
+# shortcut is taken, refused, or the scene sits close to the decision boundary.
+# ---------------------------------------------------------------------------------------------------------------
+def _box_scene(O, **light):
+    planes = O.DEFAULT_PLANES.copy().reshape(6, 12)
+    spheres = O.DEFAULT_SPHERES.copy().reshape(3, 12)
+    for k, v in light.items():
+        spheres[2, {"x": 0, "y": 1, "z": 2, "r": 3}[k]] = v
+    return planes, spheres
+
+
+@pytest.mark.parametrize("name,light", [
+    ("default (shortcut taken)", {}),
+    ("light 0.01 below the ceiling (taken, small margin)", {"y": 1.79, "r": 0.2}),
+    ("light pokes through the ceiling (refused)", {"y": 1.95, "r": 0.2}),
+    ("light touches the left wall (refused)", {"x": -2.45, "r": 0.15}),
+    ("large light near the floor and back wall (taken)", {"x": 0.5, "y": -1.2, "z": -1.9, "r": 0.75}),
+    ("light outside the room (refused, never reached)", {"y": 3.5, "r": 0.3}),
+])
+def test_shadow_ray_plane_skip_is_exact(ctx, B, O, name, light):
+    planes, spheres = _box_scene(O, **light)
+    W, H, spp = 48, 32, 12
+    ref = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC)
+    for flags in (0, B.pt_force_s(1), B.PT_KERNEL_PQ, B.PT_GENERIC_KERNEL):
+        out = ctx.pathtrace(B.pathtrace_params(W, H, spp, flags=flags), planes=planes, spheres=spheres)
+        assert np.array_equal(bits(out), bits(ref)), (name, flags)
+
+
+def test_shadow_ray_plane_skip_with_two_lights_and_mirror_walls(ctx, B, O):
+    """Two emissive spheres (both inside) and specular walls: vertices reached through mirrors still lie in the box."""
+    planes, spheres = _box_scene(O)
+    planes[0, 11] = 2.0            # left wall becomes a mirror
+    planes[4, 11] = 2.0            # back wall too
+    spheres[0, 4:7] = (30.0, 20.0, 10.0)   # the former mirror sphere now also emits
+    spheres[0, 8:11] = 0.0
+    spheres[0, 11] = 1.0
+    W, H, spp = 40, 28, 10
+    ref = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC)
+    for flags in (0, B.pt_force_s(4), B.PT_KERNEL_PQ):
+        out = ctx.pathtrace(B.pathtrace_params(W, H, spp, flags=flags), planes=planes, spheres=spheres)
+        assert np.array_equal(bits(out), bits(ref)), flags

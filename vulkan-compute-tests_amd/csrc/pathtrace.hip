@@ -48,6 +48,35 @@ bool analyse_slabs(const float* planes, uint32_t n_planes, uint32_t n_spheres, p
     return true;
 }
 
+// True when no plane can be the nearest hit of a shadow ray that reaches its light (SceneArgs::nee_skip_planes): the six
+// slabs close a box with positive extent, the camera (sensor centre and pinhole) lies inside it, and every emissive
+// sphere lies inside it with a margin far above fp32 rounding of the ray parameters.
+bool lights_inside_box(const pt::SceneArgs& sc, const float* spheres, uint32_t n_spheres, v3 cam_o, v3 cam_lc) {
+    float lo[3], hi[3], scale = 1.0f;
+    for (int a = 0; a < 3; a++) {
+        if (sc.slab_id_pos[a] < 0 || sc.slab_id_neg[a] < 0) return false;
+        lo[a] = -sc.slab_w_neg[a]; hi[a] = sc.slab_w_pos[a];
+        if (!(lo[a] < hi[a])) return false;
+        scale = std::fmax(scale, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
+    }
+    const float margin = 1e-3f * scale;
+    const float cam[2][3] = {{cam_o.x, cam_o.y, cam_o.z}, {cam_lc.x, cam_lc.y, cam_lc.z}};
+    for (auto& c : cam)
+        for (int a = 0; a < 3; a++)
+            if (!(c[a] - 0.1f > lo[a] && c[a] + 0.1f < hi[a])) return false;   // sensor half-diagonal 0.022 + pinhole 0.035
+    bool any = false;
+    for (uint32_t i = 0; i < n_spheres; i++) {
+        const float* sp = spheres + 12 * i;
+        v3 e{sp[4], sp[5], sp[6]};
+        if (!(h_dot(e, e) > 0.0f)) continue;
+        any = true;
+        if (!(sp[3] > 0.0f) || !std::isfinite(sp[3])) return false;
+        for (int a = 0; a < 3; a++)
+            if (!(sp[a] - sp[3] - margin > lo[a] && sp[a] + sp[3] + margin < hi[a])) return false;
+    }
+    return any;
+}
+
 // Sample-parallel width: enough waves to keep 256 CUs x ~28 wave slots busy with a short tail.
 int choose_S(uint64_t pixels, uint32_t samples) {
     const uint64_t target_waves = 65536;
@@ -101,6 +130,7 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
             v3 e{sp[4], sp[5], sp[6]};
             if (h_dot(e, e) > 0.0f) a.scene.emissive_mask |= 1u << i;
         }
+        a.scene.nee_skip_planes = lights_inside_box(a.scene, spheres, n_spheres, a.cam_o, a.lc) ? 1u : 0u;
     } else {      // any other scene: device buffer [records | emissive sphere indices], staged into LDS by the kernel
         std::vector<float> host((size_t)(n_planes + n_spheres) * 12 + n_spheres);
         if (n_planes) std::memcpy(host.data(), planes, sizeof(float) * 12 * n_planes);

@@ -50,7 +50,10 @@ struct v3 {
 struct SceneArgs {
     uint32_t n_planes, n_spheres;
     uint32_t emissive_mask;   // bit i set <=> dot(spheres[i].e, spheres[i].e) > 0  (pathTracer.comp:407)
-    uint32_t pad;
+    // Slab kernels: non-zero when the host proved that no plane can be the nearest hit of a shadow ray that reaches
+    // its light (closed box, camera inside, every emissive sphere inside with a margin — pathtrace.hip,
+    // lights_inside_box): the shadow `intersect` then skips the three slab tests.  Exact, see intersect().
+    uint32_t nee_skip_planes;
     float obj[(kMaxPlanes + kMaxSpheres) * 12];
     float r2[kMaxSpheres];
     // slab form of axis-aligned planes (valid only for the Slab kernels): per axis the plane whose normal
@@ -190,14 +193,24 @@ __device__ __forceinline__ bool sphere_extended(const float* sp, float r2, v3 o,
 // NP..NP+NS-1) or -1, and the ray parameter.  NP/NS < 0 select run-time counts; `obj` is the record array the
 // loops read with wave-uniform indices: the kernel-argument copy (SGPR operands) for the specialised kernels,
 // the LDS copy (broadcast ds_reads) for the generic ones.
+//
+// `shadow_skip_planes` (wave-uniform, slab kernels, shadow rays only): the caller uses nothing but "is the nearest hit
+// sphere i".  All path vertices lie in the closed box (every ray that starts inside faces the wall it is heading to),
+// the light lies inside it with a margin m, and a box is convex: a ray that hits the light does so at least m before
+// it reaches any wall, orders of magnitude beyond fp32 rounding of either quotient, so no plane can win `dd < t`
+// against that hit; when the ray misses the light the answer is "not sphere i" with or without the planes.  The
+// sphere loop is unchanged, hence the same id among spheres.
 template <bool Fast, int NP, int NS, bool Slab, int Prec>
-__device__ __forceinline__ int intersect(const SceneArgs& sc, const float* __restrict__ obj, v3 o, v3 d, float& t_out) {
+__device__ __forceinline__ int intersect(const SceneArgs& sc, const float* __restrict__ obj, v3 o, v3 d, float& t_out,
+                                         bool shadow_skip_planes = false) {
     constexpr bool LdsScene = NP < 0;
     const int np = NP >= 0 ? NP : (int)sc.n_planes;
     const int ns = NS >= 0 ? NS : (int)sc.n_spheres;
     float t = kInf;
     int id = -1;
-    if (Slab) {
+    if (Slab && shadow_skip_planes) {
+        // nothing: see above
+    } else if (Slab) {
         // Axis-aligned planes.  For n = s*e_a (s = +-1, other components +-0) and a finite ray:
         //   denom = dot(d,n) = s*d[a] exactly;  t = (w - dot(o,n)) / denom = (w - s*o[a]) / (s*d[a]).
         // The "pos" plane faces the ray iff d[a] > triEps, the "neg" plane iff -d[a] > triEps: never both.
@@ -325,7 +338,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 dm::sincos_angle<Fast>(phi, rnd.y, sphi, cphi);
                 v3 l = normalize<Fast>(((su * cphi) * sin_a + (sv * sphi) * sin_a) + sw * cos_a);   // :413
                 float tne;
-                int idne = intersect<Fast, NP, NS, Slab, Prec>(sc, uobj, x, l, tne);  // :420 shadow ray
+                int idne = intersect<Fast, NP, NS, Slab, Prec>(sc, uobj, x, l, tne, Slab && sc.nee_skip_planes != 0u);  // :420 shadow ray
                 if (idne == np + i) {
                     MC_REGION(4);   // shadow ray reached the light
                     float omega = (2.0f * kPi) * (1.0f - cos_a_max);      // :421

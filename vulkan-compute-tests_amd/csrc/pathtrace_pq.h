@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(256) pathtrace_pq_kernel(PTArgs a) {
                         dm::sincos_angle<Fast>(phi, rnd.y, sphi, cphi);
                         v3 l = normalize<Fast>(((su * cphi) * sin_a + (sv * sphi) * sin_a) + sw * cos_a);   // :413
                         float tne;
-                        int idne = intersect<Fast, NP, NS, true, 0>(sc, uobj, x, l, tne);   // :420 shadow ray
+                        int idne = intersect<Fast, NP, NS, true, 0>(sc, uobj, x, l, tne, sc.nee_skip_planes != 0u);   // :420 shadow ray
                         if (idne == NP + i) {
                             float omega = (2.0f * kPi) * (1.0f - cos_a_max);      // :421
                             A.accrad = A.accrad + ((divs<Fast>(A.accmat, kPi) * dm::gmax(dot(l, nl), 0.0f)) * le) * omega;   // :422
