@@ -9,7 +9,7 @@ A "step" is one pass of the hot path over one synthetic batch:
       HIP launch per rank — and, for N > 1, gather the fp32 row tiles to rank 0 over RCCL and
       re-assemble the storage buffer there.
   mandelbrot (BASELINE config K1): 3200 x 2400, M = 1000, fp32.  mandelbrot_ds: the two-float variant.
-Weak scaling: per-GPU work is fixed, the image grows to W x (H*N) rows, interleaved 16-row blocks per
+Weak scaling: per-GPU work is fixed, the image grows to W x (H*N) rows, interleaved 8-row blocks per
 rank (every pixel is keyed by its absolute coordinates, so tiling never changes a pixel's arithmetic;
 samples are never split across GPUs — the fp32 accumulation order is part of the parity contract).
 

@@ -2,7 +2,7 @@
 
 The path shards with NO data-path collective during the render: every pixel is independent and keyed by its
 absolute coordinates (pathTracer.comp:357,393; mandelbrot.comp:30-38), so rank r renders the interleaved
-16-row blocks r, r+n, r+2n, ... of the storage buffer with the GLOBAL (W, H) and gets the same bits as a
+8-row blocks r, r+n, r+2n, ... of the storage buffer with the GLOBAL (W, H) and gets the same bits as a
 single-GPU render.  One exchange step follows: the fp32 tiles are gathered to rank 0 (RCCL over xGMI when the
 backend is "nccl"), which re-assembles the storage buffer with mc_deinterleave_rows_device_async.
 Samples are never split across ranks: the fp32 accumulation order is part of the parity contract.
