@@ -1,0 +1,74 @@
+"""bench.py on the GPU box: the one JSON line the driver parses (contract of the task statement + tier ④), on a reduced
+workload so the test takes seconds.  The headline workload itself is what `python bench.py` runs; here we check the
+shape of the line, that the timed kernel is the HIP one, and the N = 2 code path (gloo rehearsal on one GPU: same
+sharding / gather / re-assembly code, RCCL replaced by a host-staged gather) with --verify."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(args, env_extra=None, launcher=None, timeout=600):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    cmd = [sys.executable] + (launcher or []) + [os.path.join(ROOT, "bench.py")] + args
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]          # exactly ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+def check_common(d, n, steps, warmup):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == n and d["steps"] == steps and d["warmup"] == warmup
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+
+
+def test_default_workload_line_reduced_spp():
+    d = run_bench(["--steps", "2", "--warmup", "1", "--spp", "20"])
+    check_common(d, 1, 2, 1)
+    assert d["metric"] == "path-traced samples/s" and d["unit"] == "samples/s"
+    # value = units / wall: 900*600*20 samples per step
+    assert abs(d["value"] - 900 * 600 * 20 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    # kernel time from HIP events on the launch stream is a large part of the step (nothing else is in the timed region)
+    assert 0.5 * d["ms_per_step"] < d["roofline"]["kernel_ms"] <= d["ms_per_step"] * 1.05
+    assert d["roofline"]["traffic"] is None            # not the profiled default configuration
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "samples/s" and cb["sample"]
+    assert d["value"] > 20 * cb["value"]                # a GPU, not a fallback, produced the headline
+    assert d["secondary"]["metric"] == "Mandelbrot pixel-iters/s" and d["secondary"]["pixel_iters"] == 2158756620
+    assert "strict_math" not in d                       # reported for the un-overridden headline workload only
+
+
+@pytest.mark.parametrize("workload,unit", [("mandelbrot", "pixel-iters/s"), ("mandelbrot_ds", "pixel-iters/s")])
+def test_other_workloads(workload, unit):
+    d = run_bench(["--steps", "2", "--warmup", "1", "--workload", workload, "--no-cpu-baseline"])
+    check_common(d, 1, 2, 1)
+    assert d["unit"] == unit and d["roofline"]["traffic"] is not None    # profiled configurations: bytes from profiles/
+    assert d["roofline"]["hbm"]["algorithmic_bytes"] == 3200 * 2400 * 20
+    assert abs(d["roofline"]["traffic"] - d["roofline"]["hbm"]["algorithmic_bytes"]) / d["roofline"]["traffic"] < 0.02
+
+
+def test_two_rank_rehearsal_is_bit_identical_to_one_gpu():
+    launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29533"]
+    d = run_bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--spp", "16", "--verify"],
+                  env_extra={"MC_BENCH_BACKEND": "gloo"}, launcher=launcher)
+    check_common(d, 2, 1, 1)
+    assert d["config"]["image"] == [900, 1200] and d["config"]["rows_per_gpu"] == 600
+    assert d["config"]["verified_equal_to_single_gpu"] is True
+    assert "cpu_baseline" not in d                      # rank 0 at N = 1 only
