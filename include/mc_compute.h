@@ -164,6 +164,17 @@ int mc_mandelbrot_render_rgba8(mc_context* ctx, const mc_mandelbrot_params* p, u
 int mc_pathtrace_render_rgba8(mc_context* ctx, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
                               const float* spheres, uint32_t n_spheres, uint8_t* out_rgba8);
 
+/* Host-side analysis the path tracer applies to a scene before choosing a kernel; touches no device, usable without a
+ * GPU.  *out_class: bit 0 (MC_PT_SCENE_SLAB) — six axis-aligned planes in index order x,x,y,y,z,z plus three spheres
+ * (the reference scene, pathtracerApp.h:14-39): the specialised slab kernels run; bit 1 (MC_PT_SCENE_LIGHTS_INSIDE) —
+ * additionally the planes close a box, the camera (pathTracer.comp:352) and every emissive sphere lie inside it with a
+ * margin: shadow rays (pathTracer.comp:420) skip the plane tests.  Both specialisations are bit-exact;
+ * every other scene takes the generic kernel. */
+#define MC_PT_SCENE_SLAB 1u
+#define MC_PT_SCENE_LIGHTS_INSIDE 2u
+int mc_pathtrace_scene_class(const float* planes, uint32_t n_planes, const float* spheres, uint32_t n_spheres,
+                             uint32_t* out_class);
+
 /* ---- stream / tiling helpers ------------------------------------------------------------------ */
 int mc_context_synchronize(mc_context* ctx);
 /* Number of storage rows in the tile described by (row_begin,row_end,row_block,row_stride). */

@@ -156,3 +156,52 @@ def test_apps_report_missing_device_like_the_reference(B):
         r = subprocess.run([os.path.join(bindir, exe)] + args, capture_output=True, text=True, cwd="/tmp")
         assert r.returncode == 1
         assert "starting main!" in r.stdout and "could not find a device" in r.stdout
+
+
+def test_scene_classification_host_logic(B, O):
+    """mc_pathtrace_scene_class exposes the host analysis that selects the path tracer's exact specialisations (slab
+    kernels; shadow rays that skip the walls).  The decisions below are the ones the GPU parity tests rely on
+    (tests/test_gpu_scenes.py::test_shadow_ray_plane_skip_is_exact renders the same scenes against the oracle)."""
+    SLAB, INSIDE = B.PT_SCENE_SLAB, B.PT_SCENE_LIGHTS_INSIDE
+    P = O.DEFAULT_PLANES.copy().reshape(6, 12)
+    S = O.DEFAULT_SPHERES.copy().reshape(3, 12)
+    assert B.pathtrace_scene_class(P, S) == SLAB | INSIDE           # the reference scene, pathtracerApp.h:14-39
+
+    def light(**kw):
+        s = S.copy()
+        for k, v in kw.items():
+            s[2, {"x": 0, "y": 1, "z": 2, "r": 3}[k]] = v
+        return s
+    assert B.pathtrace_scene_class(P, light(y=1.79)) == SLAB | INSIDE     # 0.01 below the ceiling: margin 7.9e-3 holds
+    assert B.pathtrace_scene_class(P, light(y=1.795)) == SLAB             # 0.005 below: inside the margin -> refused
+    assert B.pathtrace_scene_class(P, light(y=1.95)) == SLAB              # pokes through the ceiling
+    assert B.pathtrace_scene_class(P, light(x=-2.45, r=0.15)) == SLAB     # touches the left wall
+    assert B.pathtrace_scene_class(P, light(y=3.5, r=0.3)) == SLAB        # outside the room
+    assert B.pathtrace_scene_class(P, light(r=0.0)) == SLAB               # degenerate radius
+    dark = S.copy(); dark[2, 4:7] = 0
+    assert B.pathtrace_scene_class(P, dark) == SLAB                       # no emissive sphere: nothing to skip
+    two = S.copy(); two[0, 4:7] = (30, 20, 10); two[0, 1] = -1.0         # (as shipped it rests ON the floor: refused)
+    on_floor = two.copy(); on_floor[0, 1] = S[0, 1]
+    assert B.pathtrace_scene_class(P, on_floor) == SLAB
+    assert B.pathtrace_scene_class(P, two) == SLAB | INSIDE               # every emissive sphere is checked
+    two[0, 1] = -1.9                                                      # ... the second light dips through the floor
+    assert B.pathtrace_scene_class(P, two) == SLAB
+    # camera outside the box (front wall moved in front of the pinhole at z = 7.4 - 0.035)
+    near = P.copy(); near[5, 3] = 7.0
+    assert B.pathtrace_scene_class(near, S) == SLAB
+    # inverted box: the two x planes swapped offsets so that lo > hi
+    inv = P.copy(); inv[0, 3] = -3.0
+    assert B.pathtrace_scene_class(inv, S) == SLAB
+    # not an index-ordered axis-aligned box -> generic kernel
+    perm = P[[2, 3, 0, 1, 4, 5]]
+    assert B.pathtrace_scene_class(perm, S) == 0
+    tilt = P.copy(); tilt[2, :3] = (0.0, 0.99, 0.14)
+    assert B.pathtrace_scene_class(tilt, S) == 0
+    nan = P.copy(); nan[1, 3] = np.nan
+    assert B.pathtrace_scene_class(nan, S) == 0
+    assert B.pathtrace_scene_class(P[:5], S) == 0 and B.pathtrace_scene_class(P, S[:2]) == 0
+    assert B.pathtrace_scene_class(np.zeros((0, 12), np.float32), np.zeros((0, 12), np.float32)) == 0
+    # argument validation
+    out = C.c_uint32()
+    fn = B.lib().mc_pathtrace_scene_class
+    assert fn(None, 6, None, 0, C.byref(out)) == 1 and fn(None, 0, None, 0, None) == 1   # MC_ERR_INVALID_ARGUMENT

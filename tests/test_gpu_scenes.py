@@ -121,7 +121,8 @@ def test_shadow_ray_plane_skip_with_two_lights_and_mirror_walls(ctx, B, O):
     planes, spheres = _box_scene(O)
     planes[0, 11] = 2.0            # left wall becomes a mirror
     planes[4, 11] = 2.0            # back wall too
-    spheres[0, 4:7] = (30.0, 20.0, 10.0)   # the former mirror sphere now also emits
+    spheres[0, 4:7] = (30.0, 20.0, 10.0)   # the former mirror sphere now also emits ...
+    spheres[0, 1] = -1.0                   # ... and is lifted off the floor, so that the shortcut is taken
     spheres[0, 8:11] = 0.0
     spheres[0, 11] = 1.0
     W, H, spp = 40, 28, 10

@@ -169,6 +169,20 @@ def tile_rows(p):
     return int(lib().mc_tile_rows(p.row_begin, p.row_end, p.row_block, p.row_stride))
 
 
+PT_SCENE_SLAB, PT_SCENE_LIGHTS_INSIDE = 1, 2
+
+
+def pathtrace_scene_class(planes, spheres):
+    """mc_pathtrace_scene_class: which kernel specialisations the host would select for this scene (no device needed)."""
+    planes = np.ascontiguousarray(planes, np.float32).reshape(-1, 12)
+    spheres = np.ascontiguousarray(spheres, np.float32).reshape(-1, 12)
+    out = C.c_uint32(0)
+    fn = lib().mc_pathtrace_scene_class
+    fn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    _check(fn(_ptr(planes), planes.shape[0], _ptr(spheres), spheres.shape[0], C.byref(out)), "mc_pathtrace_scene_class")
+    return int(out.value)
+
+
 class Context:
     """mc_context wrapper (replaces VulkanComputeApp::init / cleanup)."""
 

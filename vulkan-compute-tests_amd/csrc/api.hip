@@ -209,6 +209,13 @@ int mc_context_synchronize(mc_context* ctx) {
     return MC_OK;
 }
 
+int mc_pathtrace_scene_class(const float* planes, uint32_t n_planes, const float* spheres, uint32_t n_spheres,
+                             uint32_t* out_class) {
+    if (!out_class || (!planes && n_planes) || (!spheres && n_spheres)) return MC_ERR_INVALID_ARGUMENT;
+    *out_class = pathtrace_scene_class(planes, n_planes, spheres, n_spheres);
+    return MC_OK;
+}
+
 uint32_t mc_tile_rows(uint32_t row_begin, uint32_t row_end, uint32_t row_block, uint32_t row_stride) {
     return tile_rows(row_begin, row_end, row_stride ? row_block : 0u, row_stride);
 }

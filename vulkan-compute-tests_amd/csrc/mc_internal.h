@@ -56,6 +56,7 @@ namespace mc {
 int mandelbrot_launch(mc_context* ctx, const mc_mandelbrot_params* p, void* d_rgba, void* d_iters, hipStream_t s);
 void mandelbrot_build_lut(uint32_t max_iter, const float k_color[4], float* lut);
 // pathtrace.hip
+uint32_t pathtrace_scene_class(const float* planes, uint32_t n_planes, const float* spheres, uint32_t n_spheres);
 int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
                      const float* spheres, uint32_t n_spheres, void* d_rgba, hipStream_t s);
 // postprocess.hip

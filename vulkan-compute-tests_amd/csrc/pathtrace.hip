@@ -77,6 +77,16 @@ bool lights_inside_box(const pt::SceneArgs& sc, const float* spheres, uint32_t n
     return any;
 }
 
+// camera — pathTracer.comp:352-353,360, evaluated once on the host with the shader's fp32 operations
+void set_camera(PTArgs& a) {
+    a.cam_o = v3{0.0f, 0.52f, 7.4f};
+    a.cam_d = h_normalize(v3{0.0f, -0.06f, -1.0f});
+    v3 up = (fabsf(a.cam_d.y) < 0.9f) ? v3{0, 1, 0} : v3{0, 0, 1};
+    a.cx = h_normalize(h_cross(a.cam_d, up));
+    a.cy = h_cross(a.cx, a.cam_d);
+    a.lc = h_add(a.cam_o, h_muls(a.cam_d, 0.035f));
+}
+
 // Sample-parallel width: enough waves to keep 256 CUs x ~28 wave slots busy with a short tail.
 int choose_S(uint64_t pixels, uint32_t samples) {
     const uint64_t target_waves = 65536;
@@ -86,6 +96,16 @@ int choose_S(uint64_t pixels, uint32_t samples) {
 }
 
 }  // namespace
+
+// Host-side scene analysis behind mc_pathtrace_scene_class (no device involved): bit 0 = the scene takes the slab
+// kernels, bit 1 = its shadow rays skip the plane tests.
+uint32_t pathtrace_scene_class(const float* planes, uint32_t n_planes, const float* spheres, uint32_t n_spheres) {
+    PTArgs a;
+    std::memset(&a, 0, sizeof(a));
+    set_camera(a);
+    if (!analyse_slabs(planes, n_planes, n_spheres, a.scene)) return 0u;
+    return 1u | (lights_inside_box(a.scene, spheres, n_spheres, a.cam_o, a.lc) ? 2u : 0u);
+}
 
 int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
                      const float* spheres, uint32_t n_spheres, void* d_rgba, hipStream_t s) {
@@ -105,13 +125,7 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
     a.sample_begin = p->sample_begin; a.sample_end = p->sample_end;
     a.max_depth = p->max_depth; a.row_begin = p->row_begin; a.row_end = p->row_end;
     a.row_block = p->row_stride ? p->row_block : 0u; a.row_stride = p->row_stride;
-    // camera — pathTracer.comp:352-353,360
-    a.cam_o = v3{0.0f, 0.52f, 7.4f};
-    a.cam_d = h_normalize(v3{0.0f, -0.06f, -1.0f});
-    v3 up = (fabsf(a.cam_d.y) < 0.9f) ? v3{0, 1, 0} : v3{0, 0, 1};
-    a.cx = h_normalize(h_cross(a.cam_d, up));
-    a.cy = h_cross(a.cx, a.cam_d);
-    a.lc = h_add(a.cam_o, h_muls(a.cam_d, 0.035f));
+    set_camera(a);
     a.out = (float4*)d_rgba;
     a.scene.n_planes = n_planes; a.scene.n_spheres = n_spheres;
     const int prec = (int)((p->flags >> 16) & 0xfu);   // MC_PT_PRECISION(x)
