@@ -104,6 +104,7 @@ def make_view(cx, cy, sx, sy):
 
 
 def mandelbrot_iters(W, H, max_iter, view=REF_VIEW, precision=0, row_begin=0, row_end=None, nthreads=0):
+    nthreads = nthreads or hardware_threads()
     row_end = H if row_end is None else row_end
     out = np.empty((row_end - row_begin, W), np.uint32)
     rc = lib().oracle_mandelbrot_iters(W, H, max_iter, np.ascontiguousarray(view, np.float32), precision, row_begin,
@@ -142,6 +143,7 @@ def pathtrace(W, H, spp, planes=DEFAULT_PLANES, spheres=DEFAULT_SPHERES, math_mo
               sample_begin=0, sample_end=None, row_begin=0, row_end=None, acc=None, nthreads=0, counts=False,
               precision=PREC_F32):
     math_mode = math_mode | (precision << 8)
+    nthreads = nthreads or hardware_threads()
     sample_end = spp if sample_end is None else sample_end
     row_end = H if row_end is None else row_end
     out = np.zeros((row_end - row_begin, W, 4), np.float32) if acc is None else np.ascontiguousarray(acc, np.float32).copy()
@@ -195,8 +197,40 @@ def mc_math(fn, x):
     return out
 
 
+def _cgroup_cpu_quota():
+    """CPUs granted by the cgroup (v2 cpu.max or v1 cfs quota), or None when unlimited / unreadable."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            return float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = float(f.read())
+        if quota > 0:
+            return quota / period
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def hardware_threads():
-    return int(lib().oracle_hardware_threads())
+    """Worker threads the oracle should use: the CPUs this process may actually run on — the smaller of the
+    hardware/affinity count and the cgroup CPU quota (a GPU box shows 256 CPUs but grants 16: 256 threads there only
+    add throttling and context switches, measured 1.06e7 vs 1.54e7 samples/s)."""
+    n = int(lib().oracle_hardware_threads())
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    q = _cgroup_cpu_quota()
+    if q:
+        n = min(n, max(1, int(q + 0.5)))
+    return max(1, n)
 
 
 # ---- oracle/_ref: the reference's own lodepng -------------------------------------------------------
