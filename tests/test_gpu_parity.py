@@ -298,6 +298,16 @@ def test_pathtrace_fast_within_tolerance(ctx, B, O):
     print(f"fast-vs-libm rmse {rmse:.4f} p99.9 {p999:.3f}; oracle mc-vs-libm rmse {yard_rmse:.4f} p99.9 {yard_p999:.3f}")
     assert rmse <= 0.75 and p999 <= 5.0
     assert abs(fast.mean() - ref.mean()) < 0.25
+    # the deviation is a handful of forked samples, not a bias: <= 2 % of the pixels move by more than half an 8-bit step,
+    # and it shrinks with spp (measured: rmse 0.56 @64 spp [one forked firefly], 0.24 @256, 0.10 @1024)
+    assert (np.abs(fast - ref).max(-1) > 0.5).mean() <= 0.02
+    spp = 256
+    fast = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST))[..., :3].astype(np.float64)
+    ref = O.pathtrace(W, H, spp, math_mode=O.MATH_LIBM)[..., :3].astype(np.float64)
+    rmse, p999 = stats(fast, ref)
+    print(f"256 spp: fast-vs-libm rmse {rmse:.4f} p99.9 {p999:.3f}")
+    assert rmse <= 0.4 and p999 <= 4.0 and abs(fast.mean() - ref.mean()) < 0.1
+    assert (np.abs(fast - ref).max(-1) > 0.5).mean() <= 0.02
 
 
 def test_pathtrace_postprocess_matches_oracle(ctx, B, O):
