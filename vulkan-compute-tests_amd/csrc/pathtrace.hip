@@ -181,9 +181,28 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
         unsigned r = 0, sp = 0;
         if (std::sscanf(e, "%u,%u", &r, &sp) == 2 && r >= 1 && r <= 64 && sp >= 1 && sp <= 64) { a.pq_regen_threshold = r; a.pq_spec_threshold = sp; }
     }
-    int rc = p->math_mode == MC_PT_MATH_FAST ? pt::launch_fast(a, variant, S, prec, rows, s)
-                                             : pt::launch_strict(a, variant, S, prec, rows, s);
-    if (rc) return rc;
+    auto launch = [&](const PTArgs& args, int width) {
+        return p->math_mode == MC_PT_MATH_FAST ? pt::launch_fast(args, variant, width, prec, rows, s)
+                                               : pt::launch_strict(args, variant, width, prec, rows, s);
+    };
+    // Ragged sample count (K2: 500 = 31 x 16 + 4): the last round of the S-wide kernel would run with S - r of every S
+    // lanes idle.  Render the full rounds, then the r remaining samples as a progressive continuation (the same
+    // mechanism a caller uses through sample_begin/sample_end: the fp32 accumulator round-trips through the storage
+    // buffer unchanged, so the sum — and its order — is the same) with a narrower sample-parallel width.
+    const uint32_t n_samples = p->sample_end - p->sample_begin;
+    const bool auto_width = ((p->flags >> 8) & 0xffu) == 0u;
+    const uint32_t rest = n_samples % (uint32_t)S;
+    if (auto_width && variant != 2 && prec == 0 && S > 1 && rest != 0u && n_samples > (uint32_t)S) {
+        PTArgs head = a, tail = a;
+        head.sample_end = tail.sample_begin = a.sample_end - rest;
+        int rc = launch(head, S);
+        if (rc) return rc;
+        rc = launch(tail, rest >= 4u ? 4 : 1);
+        if (rc) return rc;
+    } else {
+        int rc = launch(a, S);
+        if (rc) return rc;
+    }
     MC_HIP_TRY(hipGetLastError());
     return MC_OK;
 }
