@@ -9,7 +9,7 @@ A "step" is one pass of the hot path over one synthetic batch:
       HIP launch per rank — and, for N > 1, gather the fp32 row tiles to rank 0 over RCCL and
       re-assemble the storage buffer there.
   mandelbrot (BASELINE config K1): 3200 x 2400, M = 1000, fp32.  mandelbrot_ds: the two-float variant.
-Weak scaling: per-GPU work is fixed, the image grows to W x (H*N) rows, interleaved 8-row blocks per
+Weak scaling: per-GPU work is fixed, the image grows to W x (H*N) rows, interleaved row blocks (mc_row_block() = 8 rows) per
 rank (every pixel is keyed by its absolute coordinates, so tiling never changes a pixel's arithmetic;
 samples are never split across GPUs — the fp32 accumulation order is part of the parity contract).
 
@@ -135,7 +135,7 @@ def main():
         W, Hbase, spp = args.width or K2["W"], args.height or K2["H"], args.spp or K2["spp"]
         H = Hbase * n
         math_mode = B.PT_MATH_FAST if args.math == "fast" else B.PT_MATH_STRICT
-        pt_flags = int(os.environ.get("MC_PT_FLAGS", "0"), 0)    # experiments only (e.g. 2 = MC_PT_KERNEL_PQ)
+        pt_flags = int(os.environ.get("MC_PT_FLAGS", "0"), 0)    # experiments only (mc_pathtrace_params.flags)
         p = S.shard(B.pathtrace_params(W, H, spp, math_mode=math_mode, flags=pt_flags), rank, n)
         units_per_step = W * H * spp                         # samples
         flops_per_unit = FLOPS_PER_SAMPLE_PT

@@ -104,8 +104,7 @@ enum {
 
 /* mc_pathtrace_params.flags — diagnostics; every combination produces bit-identical buffers */
 enum {
-    MC_PT_GENERIC_KERNEL = 1u << 0, /* never use the axis-aligned-slab specialisation of the plane test */
-    MC_PT_KERNEL_PQ = 1u << 1       /* two-path-slots-per-lane scheduler (csrc/pathtrace_pq.h) for slab scenes */
+    MC_PT_GENERIC_KERNEL = 1u << 0 /* never use the axis-aligned-slab specialisation of the plane test */
 };
 #define MC_PT_FORCE_S(s) ((uint32_t)(s) << 8) /* force the sample-parallel width: 1, 4 or 16 (0 = automatic) */
 /* Sphere-test precision branch of pathTracer.comp:132-256.  The reference compiles every variant OUT
@@ -177,6 +176,9 @@ int mc_pathtrace_scene_class(const float* planes, uint32_t n_planes, const float
 
 /* ---- stream / tiling helpers ------------------------------------------------------------------ */
 int mc_context_synchronize(mc_context* ctx);
+/* Rows per interleave block used by every multi-GPU path of this library (mc_multi_*, bench.py's sharding): rank r of n
+ * owns the storage rows whose block index (row / mc_row_block()) is congruent to r mod n.  */
+uint32_t mc_row_block(void);
 /* Number of storage rows in the tile described by (row_begin,row_end,row_block,row_stride). */
 uint32_t mc_tile_rows(uint32_t row_begin, uint32_t row_end, uint32_t row_block, uint32_t row_stride);
 /* Reassembles the storage buffer from n_tiles interleaved tiles laid out back to back, each padded to

@@ -1,6 +1,7 @@
-"""world_size-2 test of the N > 1 path on CPU (gloo): the sharding helpers bench.py uses, with the oracle
+"""world_size 2 / 4 / 8 tests of the N > 1 path on CPU (gloo): the sharding helpers bench.py uses, with the oracle
 standing in for the renderer.  Checks that interleaved row-block tiles rendered independently, gathered to
-rank 0 and re-assembled equal the single-process image bit for bit, for both hot paths."""
+rank 0 and re-assembled equal the single-process image bit for bit, for both hot paths — including heights that
+leave a partial last block (601, 70) and worlds with more ranks than row blocks (ranks that own zero rows)."""
 import os
 import socket
 import sys
@@ -47,11 +48,14 @@ def _worker(rank, world, port, W, H, q):
         results = {}
         for name in ("mandelbrot", "pathtrace"):
             if name == "mandelbrot":
-                tile = np.stack([O.mandelbrot_iters(W, H, 100, row_begin=r, row_end=r + 1, nthreads=1)[0] for r in rows]).astype(np.int32)
+                pad = np.zeros((padded, W), np.int32)
+                for k, r in enumerate(rows):
+                    pad[k] = O.mandelbrot_iters(W, H, 100, row_begin=r, row_end=r + 1, nthreads=1)[0]
             else:
-                tile = np.concatenate([O.pathtrace(W, H, 4, math_mode=O.MATH_MC, row_begin=r, row_end=r + 1, nthreads=1) for r in rows])
-            pad = np.zeros((padded,) + tile.shape[1:], tile.dtype)
-            pad[:len(rows)] = tile
+                pad = np.zeros((padded, W, 4), np.float32)
+                for k, r in enumerate(rows):
+                    pad[k] = O.pathtrace(W, H, 4, math_mode=O.MATH_MC, row_begin=r, row_end=r + 1, nthreads=1)[0]
+            assert S.owns_rows(p) == (len(rows) > 0)
             g = S.gather_tiles(torch.from_numpy(pad), rank, world)
             if rank == 0:
                 results[name] = _deinterleave_numpy(g.numpy(), H, world, S.ROW_BLOCK)
@@ -62,9 +66,10 @@ def _worker(rank, world, port, W, H, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("H", [70, 64])
-def test_two_rank_sharded_render_equals_single(O, B, H):
-    W, world = 24, 2
+@pytest.mark.parametrize("world,H", [(2, 70), (2, 64), (4, 601), (4, 70), (8, 70), (8, 20)])
+def test_sharded_render_equals_single(O, B, world, H):
+    """(8, 20): three row blocks for eight ranks — ranks 3..7 own no rows and contribute padding only."""
+    W = 24
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -83,7 +88,7 @@ def test_two_rank_sharded_render_equals_single(O, B, H):
 def test_sharding_helpers(B):
     import __graft_entry__ as entry
     S = entry.load_package().sharding
-    for H in (600, 601, 16, 5):
+    for H in (600, 601, 70, 20, 16, 5):
         for n in (1, 2, 4, 8):
             owned = sorted(sum((S.rank_rows(H, r, n) for r in range(n)), []))
             assert owned == list(range(H))
@@ -91,6 +96,10 @@ def test_sharding_helpers(B):
     p = S.shard(B.mandelbrot_params(100, 600), 3, 8)
     assert (p.row_begin, p.row_end, p.row_block, p.row_stride) == (3 * S.ROW_BLOCK, 600, S.ROW_BLOCK, 8 * S.ROW_BLOCK)
     assert all(len(S.rank_rows(600 * n, r, n)) == 600 for n in (1, 2, 4, 8) for r in range(n))   # bench weak scaling: equal tiles
+    p = S.shard(B.mandelbrot_params(100, 20), 5, 8)      # more ranks than row blocks: rank 5 owns nothing
+    assert not S.owns_rows(p) and B.tile_rows(p) == 0 and S.rank_rows(20, 5, 8) == []
+    assert S.owns_rows(S.shard(B.mandelbrot_params(100, 20), 2, 8)) and S.rank_rows(20, 2, 8) == [16, 17, 18, 19]
+    assert S.ROW_BLOCK == B.lib().mc_row_block() == 8
     p = S.shard(B.mandelbrot_params(100, 600), 0, 1)
     assert (p.row_begin, p.row_end, p.row_block, p.row_stride) == (0, 600, 0, 0)
     with pytest.raises(RuntimeError):

@@ -12,7 +12,7 @@ def bits(a):
 
 
 VARIANTS = [("S1", lambda B: B.pt_force_s(1)), ("S4", lambda B: B.pt_force_s(4)), ("S16", lambda B: B.pt_force_s(16)),
-            ("generic", lambda B: B.PT_GENERIC_KERNEL), ("pq", lambda B: B.PT_KERNEL_PQ)]
+            ("generic", lambda B: B.PT_GENERIC_KERNEL)]
 
 
 @pytest.mark.parametrize("W,H,spp", [(1, 1, 3), (2, 1, 17), (1, 7, 5), (3, 2, 1)])
@@ -32,11 +32,12 @@ def test_depth_limits(ctx, B, O, max_depth):
         assert np.array_equal(bits(out), bits(ref)), (name, max_depth)
 
 
-def test_depth_beyond_the_pq_field_falls_back(ctx, B, O):
-    """max_depth 20 does not fit the two-slot scheduler's 4-bit depth field: the launch must fall back, not fail."""
-    ref = O.pathtrace(16, 12, 3, math_mode=O.MATH_MC, max_depth=20)
-    out = ctx.pathtrace(B.pathtrace_params(16, 12, 3, max_depth=20, flags=B.PT_KERNEL_PQ))
-    assert np.array_equal(bits(out), bits(ref))
+def test_empty_sample_range_is_rejected(ctx, B):
+    """sample_begin == sample_end used to pass validation and re-apply the gamma epilogue to a finished buffer."""
+    for sb, se in ((0, 0), (5, 5), (3, 2)):
+        with pytest.raises(B.McError) as e:
+            ctx.pathtrace(B.pathtrace_params(8, 8, 5, sample_begin=sb, sample_end=se))
+        assert e.value.status == 1    # MC_ERR_INVALID_ARGUMENT
 
 
 def test_one_row_tiles_and_last_row(ctx, B, O):

@@ -346,6 +346,45 @@ def test_multi_one_device_equals_single(ctx, B, O, monkeypatch):
             assert np.array_equal(bits(rgba), bits(lut_f[ref]))
             q = B.pathtrace_params(36, 24, 3)
             assert np.array_equal(bits(m.pathtrace(q)), bits(ctx.pathtrace(q)))
+            # a width that is not a multiple of 4 (u32 rows are not 16-B multiples): legal with one device
+            odd = B.mandelbrot_params(301, 37, max_iter=60)
+            _, ref_odd = ctx.mandelbrot(odd, want_rgba=False)
+            assert np.array_equal(m.mandelbrot(odd, want_rgba=False)[1], ref_odd)
+
+
+def test_multi_argument_errors(B):
+    """mc_multi_* argument and error paths (no second device needed)."""
+    import ctypes as C
+    L = B.lib()
+    h = C.c_void_p()
+    assert L.mc_multi_create(0, C.byref(h)) == 1 and L.mc_multi_create(1, None) == 1           # MC_ERR_INVALID_ARGUMENT
+    assert L.mc_multi_create(B.device_count() + 1, C.byref(h)) == 2 and not h.value             # MC_ERR_NO_DEVICE
+    assert L.mc_multi_destroy(None) == 0
+    with B.Multi(1) as m:
+        p = B.mandelbrot_params(64, 32)
+        assert L.mc_multi_mandelbrot_render(m._h, C.byref(p), None, None) == 1                  # no output requested
+        buf = np.empty((32, 64, 4), np.float32)
+        p.row_begin = 8                                                                         # whole image only
+        assert L.mc_multi_mandelbrot_render(m._h, C.byref(p), buf.ctypes.data_as(C.c_void_p), None) == 1
+        q = B.pathtrace_params(32, 16, 4, sample_begin=1, sample_end=4)
+        assert L.mc_multi_pathtrace_render(m._h, C.byref(q), None, 0, None, 0, buf.ctypes.data_as(C.c_void_p)) in (1, 5)
+        assert L.mc_multi_pathtrace_render(None, C.byref(q), None, 0, None, 0, buf.ctypes.data_as(C.c_void_p)) == 1
+
+
+def test_deinterleave_rows_device_4_byte_granules(ctx, B):
+    """u32 plane of an image whose width is not a multiple of 4: the 4-B granule kernel (multi-GPU iteration planes)."""
+    import torch
+    W, H, n, blk = 13, 37, 3, B.lib().mc_row_block()
+    full = torch.arange(H * W, dtype=torch.int32, device="cuda").reshape(H, W)
+    padded = B.tile_rows(B.mandelbrot_params(W, H, row_begin=0, row_end=H, row_block=blk, row_stride=n * blk))
+    tiles = torch.zeros((n, padded, W), dtype=torch.int32, device="cuda")
+    for rank in range(n):
+        rows = [r for r in range(H) if (r // blk) % n == rank]
+        tiles[rank, :len(rows)] = full[rows]
+    out = torch.empty_like(full)
+    ctx.deinterleave_rows_device(tiles.data_ptr(), W, H, n, blk, padded, 4, out.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert torch.equal(out, full)
 
 
 def test_deinterleave_rows_device(ctx, B):

@@ -101,7 +101,10 @@ def _box_scene(O, **light):
 
 @pytest.mark.parametrize("name,light", [
     ("default (shortcut taken)", {}),
-    ("light 0.01 below the ceiling (taken, small margin)", {"y": 1.79, "r": 0.2}),
+    ("light 0.05 below the ceiling (taken, just above the 0.0436 margin)", {"y": 1.75, "r": 0.2}),
+    ("light 0.04 below the ceiling (refused, just below the margin)", {"y": 1.76, "r": 0.2}),
+    ("light 0.01 below the ceiling (refused)", {"y": 1.79, "r": 0.2}),
+    ("small light 0.05 above the floor next to the back wall (taken)", {"x": 0.3, "y": -1.9, "z": -2.7, "r": 0.05}),
     ("light pokes through the ceiling (refused)", {"y": 1.95, "r": 0.2}),
     ("light touches the left wall (refused)", {"x": -2.45, "r": 0.15}),
     ("large light near the floor and back wall (taken)", {"x": 0.5, "y": -1.2, "z": -1.9, "r": 0.75}),
@@ -111,7 +114,7 @@ def test_shadow_ray_plane_skip_is_exact(ctx, B, O, name, light):
     planes, spheres = _box_scene(O, **light)
     W, H, spp = 48, 32, 12
     ref = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC)
-    for flags in (0, B.pt_force_s(1), B.PT_KERNEL_PQ, B.PT_GENERIC_KERNEL):
+    for flags in (0, B.pt_force_s(1), B.pt_force_s(16), B.PT_GENERIC_KERNEL):
         out = ctx.pathtrace(B.pathtrace_params(W, H, spp, flags=flags), planes=planes, spheres=spheres)
         assert np.array_equal(bits(out), bits(ref)), (name, flags)
 
@@ -127,6 +130,6 @@ def test_shadow_ray_plane_skip_with_two_lights_and_mirror_walls(ctx, B, O):
     spheres[0, 11] = 1.0
     W, H, spp = 40, 28, 10
     ref = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC)
-    for flags in (0, B.pt_force_s(4), B.PT_KERNEL_PQ):
+    for flags in (0, B.pt_force_s(4), B.pt_force_s(16)):
         out = ctx.pathtrace(B.pathtrace_params(W, H, spp, flags=flags), planes=planes, spheres=spheres)
         assert np.array_equal(bits(out), bits(ref)), flags

@@ -85,7 +85,7 @@ def fuzz_pathtrace(rng, ctx, B, O):
             spheres[i, 0:3] = rng.uniform(lo + 1.2, hi - 1.2).astype(np.float32)
     W, H, spp = int(rng.integers(1, 40)), int(rng.integers(1, 28)), int(rng.integers(1, 20))
     depth = int(rng.choice([12, 12, 12, 3, 7, 15]))
-    flags = int(rng.choice([0, B.pt_force_s(1), B.pt_force_s(4), B.pt_force_s(16), B.PT_KERNEL_PQ, B.PT_GENERIC_KERNEL]))
+    flags = int(rng.choice([0, B.pt_force_s(1), B.pt_force_s(4), B.pt_force_s(16), B.PT_GENERIC_KERNEL]))
     cls = B.pathtrace_scene_class(planes, spheres)
     out = ctx.pathtrace(B.pathtrace_params(W, H, spp, max_depth=depth, flags=flags), planes=planes, spheres=spheres)
     ref = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC, max_depth=depth)

@@ -20,5 +20,4 @@ def run(name, p, reps=5):
 for mode, mname in ((B.PT_MATH_FAST, "fast"), (B.PT_MATH_STRICT, "strict")):
     for S in (1, 4, 16):
         run(f"{mname} slab S={S}", B.pathtrace_params(W, H, spp, math_mode=mode, flags=B.pt_force_s(S)))
-    run(f"{mname} PQ (two slots per lane)", B.pathtrace_params(W, H, spp, math_mode=mode, flags=B.PT_KERNEL_PQ))
     run(f"{mname} generic(LDS scene) S=16", B.pathtrace_params(W, H, spp, math_mode=mode, flags=B.pt_force_s(16) | B.PT_GENERIC_KERNEL))

@@ -19,7 +19,6 @@ PRECISION_F32, PRECISION_DS = 0, 1
 PT_MATH_STRICT, PT_MATH_FAST = 0, 1
 MANDEL_FMA = 1
 PT_GENERIC_KERNEL = 1
-PT_KERNEL_PQ = 2
 PT_PREC_F32, PT_PREC_FP64, PT_PREC_DS, PT_PREC_DF64 = 0, 1, 2, 3
 DS_OPS = {"add": 0, "sub": 1, "mul": 2, "compare": 3, "sqrt": 4, "df64_add": 5, "df64_mult": 6, "df64_sqrt": 7, "twoprod": 8,
           "div": 9, "twodiff": 10, "df64_eqneq": 11, "mul_fma": 12}
@@ -81,6 +80,8 @@ def lib():
         L.mc_context_destroy.argtypes = [vp]
         L.mc_context_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(i32), C.POINTER(i32)]
         L.mc_context_synchronize.argtypes = [vp]
+        L.mc_row_block.argtypes = []
+        L.mc_row_block.restype = u32
         L.mc_tile_rows.argtypes = [u32, u32, u32, u32]
         L.mc_tile_rows.restype = u32
         L.mc_deinterleave_rows_device_async.argtypes = [vp, vp, u32, u32, u32, u32, u32, u32, vp, vp]

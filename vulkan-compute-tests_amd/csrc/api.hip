@@ -26,6 +26,24 @@ void DeviceBuffer::release() {
     ptr = nullptr; bytes = 0;
 }
 
+}  // namespace mc
+
+int mc_context::note_launch(hipStream_t s) {
+    for (auto& e : launch_events)
+        if (e.first == s) { MC_HIP_TRY(hipEventRecord(e.second, s)); return MC_OK; }
+    hipEvent_t ev = nullptr;
+    MC_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    launch_events.emplace_back(s, ev);
+    MC_HIP_TRY(hipEventRecord(ev, s));
+    return MC_OK;
+}
+int mc_context::drain_launch_streams() {
+    for (auto& e : launch_events) MC_HIP_TRY(hipEventSynchronize(e.second));
+    return MC_OK;
+}
+
+namespace mc {
+
 // The reference's scene tables — DATA from src/pathtracerApp.h:14-39 (double literals rounded to fp32
 // exactly as `static float planes[] = { .85, ... }` does).
 static const float kDefaultPlanes[6 * 12] = {
@@ -181,6 +199,8 @@ int mc_context_destroy(mc_context* ctx) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamDestroy(ctx->stream);
     }
+    for (auto& e : ctx->launch_events) { (void)hipEventSynchronize(e.second); (void)hipEventDestroy(e.second); }
+    ctx->launch_events.clear();
     ctx->lut.release();
     ctx->ctab.release();
     ctx->scratch_rgba.release();
@@ -215,6 +235,8 @@ int mc_pathtrace_scene_class(const float* planes, uint32_t n_planes, const float
     *out_class = pathtrace_scene_class(planes, n_planes, spheres, n_spheres);
     return MC_OK;
 }
+
+uint32_t mc_row_block(void) { return kRowBlock; }
 
 uint32_t mc_tile_rows(uint32_t row_begin, uint32_t row_end, uint32_t row_block, uint32_t row_stride) {
     return tile_rows(row_begin, row_end, row_stride ? row_block : 0u, row_stride);

@@ -226,10 +226,11 @@ static int ensure_lut(mc_context* ctx, const mc_mandelbrot_params* p, hipStream_
     size_t bytes = ((size_t)p->max_iter + 1) * 4 * sizeof(float);
     std::vector<float> host(((size_t)p->max_iter + 1) * 4);
     mandelbrot_build_lut(p->max_iter, p->k_color, host.data());
-    // a previous launch may still be reading the old table on another stream: drain before replacing it
-    MC_HIP_TRY(hipDeviceSynchronize());
-    int rc = ctx->lut.reserve(bytes);
+    // a previous launch of this context may still be reading the old table (possibly on another stream): wait for
+    // the streams this context has launched on — not the whole device — before replacing it
+    int rc = ctx->drain_launch_streams();
     if (rc) return rc;
+    if ((rc = ctx->lut.reserve(bytes))) return rc;
     MC_HIP_TRY(hipMemcpyAsync(ctx->lut.ptr, host.data(), bytes, hipMemcpyHostToDevice, s));
     MC_HIP_TRY(hipStreamSynchronize(s));   // host vector goes out of scope
     ctx->lut_max_iter = p->max_iter;
@@ -263,9 +264,9 @@ static int ensure_c_table(mc_context* ctx, const mc_mandelbrot_params* p, hipStr
             tab[g] = c_hi + (u - 0.5f) * s_hi;
         }
     }
-    MC_HIP_TRY(hipDeviceSynchronize());   // an earlier launch may still read the old table
-    int rc = ctx->ctab.reserve(tab.size() * sizeof(float));
+    int rc = ctx->drain_launch_streams();   // an earlier launch of this context may still read the old table
     if (rc) return rc;
+    if ((rc = ctx->ctab.reserve(tab.size() * sizeof(float)))) return rc;
     MC_HIP_TRY(hipMemcpyAsync(ctx->ctab.ptr, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, s));
     MC_HIP_TRY(hipStreamSynchronize(s));
     ctx->ctab_key = key;
@@ -306,7 +307,7 @@ int mandelbrot_launch(mc_context* ctx, const mc_mandelbrot_params* p, void* d_rg
         hipLaunchKernelGGL((mandelbrot_kernel<StateF32<false>, 8>), grid, block, 0, s, a);
     }
     MC_HIP_TRY(hipGetLastError());
-    return MC_OK;
+    return ctx->note_launch(s);
 }
 
 }  // namespace mc

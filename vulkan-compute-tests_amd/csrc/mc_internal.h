@@ -48,6 +48,12 @@ struct mc_context {
     // generic path-tracer scenes: device copy of [records | emissive indices] and the host copy it mirrors
     mc::DeviceBuffer scene_buf;
     std::vector<float> scene_host;
+    // One event per stream this context has launched on, re-recorded after every launch that reads a cached table
+    // (LUT, c table, scene records).  Replacing a table waits for these events only — never hipDeviceSynchronize():
+    // other contexts and unrelated streams keep running.  The stream handle is only a key (an event outlives its stream).
+    std::vector<std::pair<hipStream_t, hipEvent_t>> launch_events;
+    int note_launch(hipStream_t s);
+    int drain_launch_streams();
 };
 
 namespace mc {
@@ -79,6 +85,13 @@ inline uint32_t tile_rows(uint32_t row_begin, uint32_t row_end, uint32_t B, uint
     uint32_t full = span / stride, rem = span - full * stride;
     return full * B + (rem < B ? rem : B);
 }
+
+// Rows per interleave block of the multi-GPU row tiling — ONE value for mc_multi_* (multi.hip), sharding.py (through
+// mc_row_block()) and the docs.  8: every BASELINE configuration splits into whole blocks per rank at N = 1, 2, 4, 8
+// (K2 weak-scaled 600*N rows -> 75 blocks per rank, K3 2560 -> 320 blocks, K4 5120 -> 640), a wave's 8x8 / 4x4 / 2x2
+// pixel tile stays inside one block, and Mandelbrot's interior rows are spread evenly.  Any value is legal:
+// tile-local rows map to storage rows one by one (tile_row_to_storage).
+constexpr uint32_t kRowBlock = 8;
 
 inline hipStream_t pick_stream(mc_context* ctx, void* stream) { return stream ? (hipStream_t)stream : ctx->stream; }
 

@@ -36,8 +36,6 @@ namespace mc {
         }                                                                                       \
     } while (0)
 
-constexpr uint32_t kRowBlock = 16;   // rows per interleave block = the kernels' 16-row thread-block tile
-
 // Gathers equal-sized tiles (count elements of `type` per rank) to device 0 and de-interleaves them.
 static int gather_and_assemble(mc_multi* m, std::vector<DeviceBuffer>& tiles, DeviceBuffer& gathered, DeviceBuffer& full,
                                uint32_t W, uint32_t H, uint32_t tile_rows_padded, uint32_t bpp) {
@@ -71,6 +69,10 @@ static int gather_and_assemble(mc_multi* m, std::vector<DeviceBuffer>& tiles, De
         MC_HIP_TRY(hipMemcpyAsync(gathered.ptr, tiles[0].ptr, tile_bytes, hipMemcpyDeviceToDevice, c0->stream));
     }
     MC_HIP_TRY(hipSetDevice(c0->device));
+    if (m->n == 1) {   // one tile = the image in storage order already: no row shuffle, any width
+        MC_HIP_TRY(hipMemcpyAsync(full.ptr, gathered.ptr, (size_t)W * H * bpp, hipMemcpyDeviceToDevice, c0->stream));
+        return MC_OK;
+    }
     return deinterleave_rows_launch(c0, gathered.ptr, W, H, (uint32_t)m->n, kRowBlock, tile_rows_padded, bpp, full.ptr,
                                     c0->stream);
 }
@@ -147,7 +149,6 @@ static int multi_mandelbrot(mc_multi* m, const mc_mandelbrot_params* p, float* o
     if (!m || !p || (!out_rgba_f32 && !out_iters && !out_rgba8)) return MC_ERR_INVALID_ARGUMENT;
     const bool want_rgba = out_rgba_f32 || out_rgba8;
     if (p->row_begin != 0 || p->row_end != p->height || p->row_stride) return MC_ERR_INVALID_ARGUMENT;   // whole image only
-    if ((p->width % 4u) != 0 && out_iters && m->n > 1) return MC_ERR_UNSUPPORTED;   // 16-B row granules for the u32 plane
     const uint32_t W = p->width, H = p->height;
     const uint32_t padded = padded_tile_rows(H, m->n);
     int rc;

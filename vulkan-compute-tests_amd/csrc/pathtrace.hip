@@ -50,7 +50,12 @@ bool analyse_slabs(const float* planes, uint32_t n_planes, uint32_t n_spheres, p
 
 // True when no plane can be the nearest hit of a shadow ray that reaches its light (SceneArgs::nee_skip_planes): the six
 // slabs close a box with positive extent, the camera (sensor centre and pinhole) lies inside it, and every emissive
-// sphere lies inside it with a margin far above fp32 rounding of the ray parameters.
+// sphere lies inside it with a margin above the fp32 error of the two ray parameters being compared.
+// Error bound behind the margin: the wall parameter (w - o[a]) / d[a] is good to a few ulp, but the sphere root
+// b - sqrt(b*b - |oc|^2 + r^2) of a GRAZING shadow ray is not: det carries an absolute error of a few ulp(b*b)
+// <= 4 eps |oc|^2, and sqrt turns that into up to 2 sqrt(eps) |oc| ~ 7e-4 |oc|, with |oc| <= 2 sqrt(3) scale for
+// points of the box.  kMarginFactor * sqrt(eps) * scale = 5.5e-3 * scale leaves a factor >2 over that bound
+// (tests/test_gpu_scenes.py renders scenes just above and just below it against the oracle).
 bool lights_inside_box(const pt::SceneArgs& sc, const float* spheres, uint32_t n_spheres, v3 cam_o, v3 cam_lc) {
     float lo[3], hi[3], scale = 1.0f;
     for (int a = 0; a < 3; a++) {
@@ -59,7 +64,8 @@ bool lights_inside_box(const pt::SceneArgs& sc, const float* spheres, uint32_t n
         if (!(lo[a] < hi[a])) return false;
         scale = std::fmax(scale, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
     }
-    const float margin = 1e-3f * scale;
+    constexpr float kMarginFactor = 16.0f;
+    const float margin = kMarginFactor * sqrtf(1.1920929e-7f) * scale;
     const float cam[2][3] = {{cam_o.x, cam_o.y, cam_o.z}, {cam_lc.x, cam_lc.y, cam_lc.z}};
     for (auto& c : cam)
         for (int a = 0; a < 3; a++)
@@ -111,7 +117,7 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
                      const float* spheres, uint32_t n_spheres, void* d_rgba, hipStream_t s) {
     if (!ctx || !p || !d_rgba || (!planes && n_planes) || (!spheres && n_spheres)) return MC_ERR_INVALID_ARGUMENT;
     if (!p->width || !p->height || !p->spp || p->row_end > p->height || p->row_begin >= p->row_end ||
-        p->sample_end > p->spp || p->sample_begin > p->sample_end)
+        p->sample_end > p->spp || p->sample_begin >= p->sample_end)   // an empty range would re-apply the epilogue (:453)
         return MC_ERR_INVALID_ARGUMENT;
     if (p->math_mode != MC_PT_MATH_STRICT && p->math_mode != MC_PT_MATH_FAST) return MC_ERR_INVALID_ARGUMENT;
     if (p->row_stride && (!p->row_block || p->row_block > p->row_stride)) return MC_ERR_INVALID_ARGUMENT;
@@ -158,11 +164,15 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
         }
         host.resize((size_t)(n_planes + n_spheres) * 12 + n_em);
         if (host != ctx->scene_host || !ctx->scene_buf.ptr) {            // upload only when the scene changed
-            MC_HIP_TRY(hipDeviceSynchronize());                          // an earlier launch may still read the old copy
-            int rc = ctx->scene_buf.reserve(host.size() * sizeof(float) + 16);
+            // Earlier launches of THIS context may still read the old copy: wait for the streams it has launched on
+            // (never the whole device — other contexts and streams keep running), then upload in stream order.
+            int rc = ctx->drain_launch_streams();
             if (rc) return rc;
-            MC_HIP_TRY(hipMemcpy(ctx->scene_buf.ptr, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
-            ctx->scene_host = host;
+            if ((rc = ctx->scene_buf.reserve(host.size() * sizeof(float) + 16))) return rc;
+            ctx->scene_host = host;   // the async copy below reads ctx->scene_host, which outlives it
+            MC_HIP_TRY(hipMemcpyAsync(ctx->scene_buf.ptr, ctx->scene_host.data(), host.size() * sizeof(float),
+                                      hipMemcpyHostToDevice, s));
+            MC_HIP_TRY(hipStreamSynchronize(s));   // pageable source: the copy is staged before the call returns anyway
         }
         a.scene.d_obj = (const float*)ctx->scene_buf.ptr;
         a.scene.d_emissive = (const uint32_t*)((const float*)ctx->scene_buf.ptr + (size_t)(n_planes + n_spheres) * 12);
@@ -173,14 +183,7 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
     if (S == 0) S = choose_S((uint64_t)rows * p->width, p->sample_end - p->sample_begin);
     if (S != 1 && S != 4 && S != 16) return MC_ERR_INVALID_ARGUMENT;
     if (prec != 0 && S == 4) S = (p->sample_end - p->sample_begin) >= 16 ? 16 : 1;   // precision variants exist for S = 1, 16
-    int variant = slab ? 1 : 0;
-    // two-path-slots-per-lane scheduler (pathtrace_pq.h): slab scenes, depth fits its 4-bit field
-    if (slab && (p->flags & MC_PT_KERNEL_PQ) && p->max_depth <= 15u) variant = 2;
-    a.pq_regen_threshold = 24u; a.pq_spec_threshold = 16u;
-    if (const char* e = std::getenv("MC_PT_PQ_THRESHOLDS")) {   // experiments: "regen,spec"
-        unsigned r = 0, sp = 0;
-        if (std::sscanf(e, "%u,%u", &r, &sp) == 2 && r >= 1 && r <= 64 && sp >= 1 && sp <= 64) { a.pq_regen_threshold = r; a.pq_spec_threshold = sp; }
-    }
+    const int variant = slab ? 1 : 0;
     auto launch = [&](const PTArgs& args, int width) {
         return p->math_mode == MC_PT_MATH_FAST ? pt::launch_fast(args, variant, width, prec, rows, s)
                                                : pt::launch_strict(args, variant, width, prec, rows, s);
@@ -192,7 +195,7 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
     const uint32_t n_samples = p->sample_end - p->sample_begin;
     const bool auto_width = ((p->flags >> 8) & 0xffu) == 0u;
     const uint32_t rest = n_samples % (uint32_t)S;
-    if (auto_width && variant != 2 && prec == 0 && S > 1 && rest != 0u && n_samples > (uint32_t)S) {
+    if (auto_width && prec == 0 && S > 1 && rest != 0u && n_samples > (uint32_t)S) {
         PTArgs head = a, tail = a;
         head.sample_end = tail.sample_begin = a.sample_end - rest;
         int rc = launch(head, S);
@@ -204,7 +207,7 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
         if (rc) return rc;
     }
     MC_HIP_TRY(hipGetLastError());
-    return MC_OK;
+    return slab ? MC_OK : ctx->note_launch(s);   // only the generic kernels read a cached device table
 }
 
 }  // namespace mc

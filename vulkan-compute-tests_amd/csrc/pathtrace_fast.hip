@@ -14,15 +14,10 @@
 #include "mc_math.h"
 #pragma clang fp contract(fast)   // (reassociate(on) on top of this was tried: 697 vs 700 VALU instructions, not kept)
 #include "pathtrace_kernel.h"
-#include "pathtrace_pq.h"
 
 namespace mc {
 namespace pt {
 int launch_fast(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s) {
-    if (variant == 2) {   // two-path-slots-per-lane scheduler (pathtrace_pq.h), slab scenes only
-        launch_pq<true>(a, tile_rows, s);
-        return MC_OK;
-    }
     return launch_impl<true>(a, variant, S, prec, tile_rows, s);
 }
 }  // namespace pt

@@ -71,7 +71,6 @@ struct SceneArgs {
 
 struct PTArgs {
     uint32_t W, H, spp, sample_begin, sample_end, max_depth, row_begin, row_end, row_block, row_stride;
-    uint32_t pq_regen_threshold, pq_spec_threshold;   // pathtrace_pq.h scheduler thresholds (lanes)
     // camera basis (pathTracer.comp:352-353,360), evaluated once on the host with the same IEEE ops
     v3 cam_o, cam_d, cx, cy, lc;
     float4* __restrict__ out;   // tile-local storage rows
@@ -471,39 +470,42 @@ inline size_t scene_lds_bytes(const PTArgs& a) {
 constexpr size_t kMaxSceneLdsBytes = 144u * 1024u;   // of the 160 KB per CU: 3072 objects
 
 template <bool Fast, int NP, int NS, bool Slab, int S, int Prec>
-inline void launch_one(const PTArgs& a, uint32_t tile_rows, hipStream_t s) {
+inline int launch_one(const PTArgs& a, uint32_t tile_rows, hipStream_t s) {
     dim3 grid((a.W + block_w<S>() - 1u) / block_w<S>(), (tile_rows + block_h<S>() - 1u) / block_h<S>());
     const size_t lds = scene_lds_bytes(a);
     auto kern = pathtrace_kernel<Fast, NP, NS, Slab, S, Prec>;
-    if (lds > 48u * 1024u)   // beyond the default dynamic-LDS window: opt in (gfx950 has 160 KB per CU)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48u * 1024u) {   // beyond the default dynamic-LDS window: opt in (gfx950 has 160 KB per CU)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error_detail(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
+            return MC_ERR_HIP;
+        }
+    }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    return MC_OK;
 }
 
 template <bool Fast>
 inline int launch_impl(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s) {
     if (prec == 0) {
         if (variant == 1) {
-            if (S == 1) launch_one<Fast, 6, 3, true, 1, 0>(a, tile_rows, s);
-            else if (S == 4) launch_one<Fast, 6, 3, true, 4, 0>(a, tile_rows, s);
-            else if (S == 16) launch_one<Fast, 6, 3, true, 16, 0>(a, tile_rows, s);
-            else return MC_ERR_INVALID_ARGUMENT;
+            if (S == 1) return launch_one<Fast, 6, 3, true, 1, 0>(a, tile_rows, s);
+            if (S == 4) return launch_one<Fast, 6, 3, true, 4, 0>(a, tile_rows, s);
+            if (S == 16) return launch_one<Fast, 6, 3, true, 16, 0>(a, tile_rows, s);
         } else {
-            if (S == 1) launch_one<Fast, -1, -1, false, 1, 0>(a, tile_rows, s);
-            else if (S == 4) launch_one<Fast, -1, -1, false, 4, 0>(a, tile_rows, s);
-            else if (S == 16) launch_one<Fast, -1, -1, false, 16, 0>(a, tile_rows, s);
-            else return MC_ERR_INVALID_ARGUMENT;
+            if (S == 1) return launch_one<Fast, -1, -1, false, 1, 0>(a, tile_rows, s);
+            if (S == 4) return launch_one<Fast, -1, -1, false, 4, 0>(a, tile_rows, s);
+            if (S == 16) return launch_one<Fast, -1, -1, false, 16, 0>(a, tile_rows, s);
         }
-        return MC_OK;
+        return MC_ERR_INVALID_ARGUMENT;
     }
     if (S != 1 && S != 16) return MC_ERR_INVALID_ARGUMENT;
     switch (prec) {
-        case 1: if (S == 1) launch_one<Fast, -1, -1, false, 1, 1>(a, tile_rows, s); else launch_one<Fast, -1, -1, false, 16, 1>(a, tile_rows, s); break;
-        case 2: if (S == 1) launch_one<Fast, -1, -1, false, 1, 2>(a, tile_rows, s); else launch_one<Fast, -1, -1, false, 16, 2>(a, tile_rows, s); break;
-        case 3: if (S == 1) launch_one<Fast, -1, -1, false, 1, 3>(a, tile_rows, s); else launch_one<Fast, -1, -1, false, 16, 3>(a, tile_rows, s); break;
+        case 1: return S == 1 ? launch_one<Fast, -1, -1, false, 1, 1>(a, tile_rows, s) : launch_one<Fast, -1, -1, false, 16, 1>(a, tile_rows, s);
+        case 2: return S == 1 ? launch_one<Fast, -1, -1, false, 1, 2>(a, tile_rows, s) : launch_one<Fast, -1, -1, false, 16, 2>(a, tile_rows, s);
+        case 3: return S == 1 ? launch_one<Fast, -1, -1, false, 1, 3>(a, tile_rows, s) : launch_one<Fast, -1, -1, false, 16, 3>(a, tile_rows, s);
         default: return MC_ERR_INVALID_ARGUMENT;
     }
-    return MC_OK;
 }
 
 }  // namespace pt

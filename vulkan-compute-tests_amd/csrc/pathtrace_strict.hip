@@ -1,15 +1,10 @@
 // Instantiates the MC_PT_MATH_STRICT path tracer kernels (IEEE divide/sqrt + mc_math sin/cos/pow:
 // bit-identical to the CPU oracle).  Split from the fast instantiations so both compile in parallel.
 #include "pathtrace_kernel.h"
-#include "pathtrace_pq.h"
 
 namespace mc {
 namespace pt {
 int launch_strict(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s) {
-    if (variant == 2) {   // two-path-slots-per-lane scheduler (pathtrace_pq.h), slab scenes only
-        launch_pq<false>(a, tile_rows, s);
-        return MC_OK;
-    }
     return launch_impl<false>(a, variant, S, prec, tile_rows, s);
 }
 }  // namespace pt

@@ -40,8 +40,10 @@ __global__ void __launch_bounds__(256) convert_rgba8_kernel(const float4* __rest
 }
 
 // Rebuilds the storage buffer from interleaved tiles (the layout an RCCL gather leaves on the root):
-// storage row r = (k*n_tiles + t)*B + j  <-  tile t, tile row k*B + j.  16-B granules, HBM-bound.
-__global__ void __launch_bounds__(256) deinterleave_rows_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
+// storage row r = (k*n_tiles + t)*B + j  <-  tile t, tile row k*B + j.  HBM-bound; 16-B granules (uint4) whenever a row
+// is a multiple of 16 B, 4-B granules otherwise (the uint32 iteration plane of an image whose width is not a multiple of 4).
+template <class G>
+__global__ void __launch_bounds__(256) deinterleave_rows_kernel(const G* __restrict__ src, G* __restrict__ dst,
                                                                 uint32_t row_granules, uint32_t H, uint32_t n_tiles,
                                                                 uint32_t B, uint32_t tile_rows_padded) {
     const size_t total = (size_t)row_granules * H;
@@ -60,14 +62,19 @@ int deinterleave_rows_launch(mc_context* ctx, const void* d_tiles, uint32_t W, u
                              uint32_t tile_rows_padded, uint32_t bytes_per_pixel, void* d_out, hipStream_t s) {
     if (!ctx || !d_tiles || !d_out || !W || !H || !n_tiles || !B) return MC_ERR_INVALID_ARGUMENT;
     size_t row_bytes = (size_t)W * bytes_per_pixel;
-    if ((bytes_per_pixel != 16 && bytes_per_pixel != 4) || (row_bytes % 16) != 0) return MC_ERR_INVALID_ARGUMENT;
-    uint32_t row_granules = (uint32_t)(row_bytes / 16);
+    if (bytes_per_pixel != 16 && bytes_per_pixel != 4) return MC_ERR_INVALID_ARGUMENT;
+    const bool wide = (row_bytes % 16) == 0;   // hipMalloc'ed tiles are 256-B aligned, so every row then starts on a 16-B boundary
+    uint32_t row_granules = (uint32_t)(row_bytes / (wide ? 16 : 4));
     size_t total = (size_t)row_granules * H;
     uint32_t blocks = (uint32_t)((total + 255) / 256);
     uint32_t cap = (uint32_t)ctx->props.multiProcessorCount * 8u;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(deinterleave_rows_kernel, dim3(blocks), dim3(256), 0, s, (const uint4*)d_tiles, (uint4*)d_out,
-                       row_granules, H, n_tiles, B, tile_rows_padded);
+    if (wide)
+        hipLaunchKernelGGL(deinterleave_rows_kernel<uint4>, dim3(blocks), dim3(256), 0, s, (const uint4*)d_tiles, (uint4*)d_out,
+                           row_granules, H, n_tiles, B, tile_rows_padded);
+    else
+        hipLaunchKernelGGL(deinterleave_rows_kernel<uint32_t>, dim3(blocks), dim3(256), 0, s, (const uint32_t*)d_tiles,
+                           (uint32_t*)d_out, row_granules, H, n_tiles, B, tile_rows_padded);
     MC_HIP_TRY(hipGetLastError());
     return MC_OK;
 }

@@ -2,7 +2,7 @@
 
 The path shards with NO data-path collective during the render: every pixel is independent and keyed by its
 absolute coordinates (pathTracer.comp:357,393; mandelbrot.comp:30-38), so rank r renders the interleaved
-8-row blocks r, r+n, r+2n, ... of the storage buffer with the GLOBAL (W, H) and gets the same bits as a
+ROW_BLOCK-row blocks r, r+n, r+2n, ... of the storage buffer with the GLOBAL (W, H) and gets the same bits as a
 single-GPU render.  One exchange step follows: the fp32 tiles are gathered to rank 0 (RCCL over xGMI when the
 backend is "nccl"), which re-assembles the storage buffer with mc_deinterleave_rows_device_async.
 Samples are never split across ranks: the fp32 accumulation order is part of the parity contract.
@@ -10,8 +10,9 @@ Samples are never split across ranks: the fp32 accumulation order is part of the
 import torch
 import torch.distributed as dist
 
-ROW_BLOCK = 8    # 600*N rows (bench weak scaling) split into exactly 75 blocks per rank; any block height is legal
-                 # (tile-local rows are mapped to storage rows one by one), 8 keeps a wave's 8x8 / 4x4 / 2x2 tile whole
+from . import bindings as _b
+
+ROW_BLOCK = int(_b.lib().mc_row_block())   # the library's one interleave-block height (csrc/mc_internal.h kRowBlock = 8)
 
 
 def shard(p, rank, n, block=ROW_BLOCK):
@@ -21,6 +22,12 @@ def shard(p, rank, n, block=ROW_BLOCK):
     else:
         p.row_begin, p.row_end, p.row_block, p.row_stride = rank * block, p.height, block, block * n
     return p
+
+
+def owns_rows(p):
+    """False for a rank whose first row block lies beyond the image (more ranks than blocks): it launches nothing and
+    contributes only padding to the gather."""
+    return p.row_begin < p.row_end
 
 
 def rank_rows(height, rank, n, block=ROW_BLOCK):
