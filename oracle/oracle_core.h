@@ -163,6 +163,7 @@ struct PlainPolicy {
     static inline void c_cvt(int = 1) {}
     static inline void c_intersect() {}
     static inline void c_bounce() {}
+    static inline void c_material(int) {}   // hook: the material branch a surviving bounce takes (tools/sched_sim.cpp)
     static inline void c_sample() {}
 };
 struct CountPolicy {
@@ -179,6 +180,7 @@ struct CountPolicy {
     static inline void c_cvt(int n = 1) { tls_counts()->cvt += n; }
     static inline void c_intersect() { tls_counts()->intersect_calls++; }
     static inline void c_bounce() { tls_counts()->bounces++; }
+    static inline void c_material(int) {}
     static inline void c_sample() { tls_counts()->samples++; }
 };
 
@@ -650,6 +652,7 @@ struct PT {
                 if (rnd.z >= p) break;                                     // :396
                 else accmat = divs(accmat, p);                             // :397
             }
+            P::c_material(mat);
             if (mat == 1) {                                                // :400 diffuse
                 for (uint32_t i = 0; i < nSpheres; i++) {                  // :403
                     const float* ls = spheres + 12 * i;

@@ -1,0 +1,257 @@
+// Scheduling simulator for the path tracer's lane-regrouping kernel — a design tool, not product code.
+//
+// Traces real paths of the default scene with the CPU oracle (TEST INFRASTRUCTURE, oracle/oracle_core.h), records for
+// every sample the sequence of events "bounce k hit material m / was terminated by Russian roulette", and replays those
+// sequences through models of the kernels' lane schedulers with a VALU-issue cost per code block:
+//   rounds : the round-synchronous kernel of round 1 (a wave = 4 pixels x 16 samples, all lanes step together)
+//   regroup: the round-2 scheduler — workgroup-shared FIFOs of parked paths; a wave keeps its diffuse paths in registers,
+//            parks specular ones, refills vacated lanes with diffuse-ready paths, and when it cannot, spills its lanes and
+//            runs a full-width batch of {parked specular paths + fresh camera samples}.
+// Prints issued-instruction cost per sample, active-lane fraction, queue high-water marks and the reorder window, so that
+// thresholds / capacities can be chosen before spending GPU time.
+//
+// Build: g++ -O2 -std=c++17 -ffp-contract=off -o tools/bin/sched_sim tools/sched_sim.cpp
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "../oracle/oracle_core.h"
+
+namespace {
+
+thread_local std::vector<uint8_t>* g_events = nullptr;
+struct TracePolicy : oracle::PlainPolicy {
+    static inline void c_bounce() { g_events->push_back(0); }             // a hit; stays 0 if RR terminates it
+    static inline void c_material(int m) { g_events->back() = (uint8_t)m; }
+};
+
+const float kPlanes[6 * 12] = {
+    -1.0f, +0.0f, +0.0f, +2.6f, 0, 0, 0, 0, .85f, .25f, .25f, 1, +1.0f, +0.0f, +0.0f, +2.6f, 0, 0, 0, 0, .25f, .35f, .85f, 1,
+    +0.0f, +1.0f, +0.0f, +2.0f, 0, 0, 0, 0, .75f, .75f, .75f, 1, +0.0f, -1.0f, +0.0f, +2.0f, 0, 0, 0, 0, .75f, .75f, .75f, 1,
+    +0.0f, +0.0f, -1.0f, +2.8f, 0, 0, 0, 0, .85f, .85f, .25f, 1, +0.0f, +0.0f, +1.0f, +7.9f, 0, 0, 0, 0, 0.1f, 0.7f, 0.7f, 1,
+};
+const float kSpheres[3 * 12] = {
+    -1.3f, -1.2f, -1.3f, 0.8f, 0, 0, 0, 0, .999f, .999f, .999f, 2, 1.3f, -1.2f, -0.2f, 0.8f, 0, 0, 0, 0, .999f, .999f, .999f, 3,
+    0, 1.6f, 0, 0.2f, 100, 100, 100, 0, 0, 0, 0, 1,
+};
+
+// ---- cost model: VALU wave-instructions per execution of a code block (DESIGN.md §3.3 region counters) ----
+struct Cost {
+    double ip = 284, d = 320, g = 93, m = 30, cam = 100;
+    double ov_iter = 40;      // swap-point bookkeeping per scheduler iteration (ballots, prefix sums, LDS addressing)
+    double ov_batch = 60;     // extra per S-batch (spill + reload addressing)
+    double fold_round = 96;   // rounds kernel: ordered fold of 16 samples x 4 pixels
+    double commit_item = 1.5; // regroup kernel: ordered commit, per item
+};
+
+struct Path {
+    const uint8_t* ev;   // events: per bounce 0 = RR-terminated after intersect+prologue, 1/2/3 = material executed
+    int n;               // number of hits recorded (a miss ends the list early)
+    int max_depth;
+};
+
+struct Tile { std::vector<std::vector<uint8_t>> samples; };   // [pixel * spp + s]
+
+struct Stats {
+    double cost = 0, useful = 0;          // issued wave-instructions, lane-weighted useful share (x64)
+    double iters = 0;
+    long n_samples = 0;
+    int max_dq = 0, max_sq = 0, max_window = 0;
+    double stall_lane_iters = 0;
+};
+
+// ---------------------------------------------------------------- rounds kernel (round 1)
+void sim_rounds(const Tile& t, int pixels, int spp, int max_depth, const Cost& c, Stats& st) {
+    // a wave = 4 pixels x 16 samples; a block's 16 pixels are 4 such waves
+    for (int p0 = 0; p0 < pixels; p0 += 4) {
+        for (int base = 0; base < spp; base += 16) {
+            int pos[64], alive[64], kind[64];
+            const std::vector<uint8_t>* ev[64];
+            int n = 0;
+            for (int l = 0; l < 64; l++) {
+                int p = p0 + l / 16, s = base + l % 16;
+                alive[l] = s < spp;
+                ev[l] = alive[l] ? &t.samples[(size_t)p * spp + s] : nullptr;
+                pos[l] = 0;
+                n += alive[l];
+            }
+            st.cost += c.cam + c.fold_round; st.useful += n * (c.cam + c.fold_round) / 64.0 * 64.0 / 64.0 * 1.0;
+            st.n_samples += n;
+            for (int depth = 0; depth < max_depth; depth++) {
+                int na = 0, nd = 0, ng = 0, nm = 0;
+                for (int l = 0; l < 64; l++) {
+                    kind[l] = -1;
+                    if (!alive[l]) continue;
+                    na++;
+                    if (pos[l] >= (int)ev[l]->size()) { alive[l] = 0; continue; }   // miss: intersect ran, nothing else
+                    int e = (*ev[l])[pos[l]++];
+                    kind[l] = e;
+                    if (e == 0) alive[l] = 0;
+                    else if (e == 1) nd++;
+                    else if (e == 2) nm++;
+                    else ng++;
+                }
+                if (!na) break;
+                st.iters += 1;
+                st.cost += c.ip + (nd ? c.d : 0) + (ng ? c.g : 0) + (nm ? c.m : 0);
+                st.useful += (na * c.ip + nd * c.d + ng * c.g + nm * c.m) / 64.0;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- regroup kernel (round 2)
+struct Rec { int item; int pos; int kind; };   // kind: 1 D-ready, 2/3 specular pending, 4 camera (fresh)
+
+struct RegroupCfg {
+    int waves = 4;          // waves per workgroup sharing the queues
+    int dq_cap = 128, sq_cap = 128;
+    int window = 1024;      // reorder ring entries per workgroup (items in flight)
+    int s_batch_min = 48;   // run an S-batch only if parked specular + fresh camera items reach this many
+    bool share = true;
+};
+
+void sim_regroup(const Tile& t, int pix0, int pixels, int spp, int max_depth, const Cost& c, const RegroupCfg& cfg, Stats& st) {
+    const int total_items = pixels * spp;   // item k -> pixel k % pixels, sample k / pixels
+    int next_item = 0;
+    std::vector<char> done(total_items, 0);
+    int committed = 0;                       // all items < committed are done (conservative window base)
+    std::vector<Rec> dq, sq;                 // FIFOs
+    struct Wave { Rec lane[64]; double clock = 0; bool finished = false; };
+    std::vector<Wave> W(cfg.waves);
+    for (auto& w : W) for (auto& l : w.lane) l.kind = 0;
+    auto path = [&](int item) -> const std::vector<uint8_t>& { return t.samples[(size_t)(pix0 + item % pixels) * spp + item / pixels]; };
+    auto retire = [&](int item) {
+        done[item] = 1;
+        while (committed < total_items && done[committed]) committed++;
+    };
+    int live_waves = cfg.waves;
+    while (live_waves) {
+        // the wave with the smallest clock runs next (asynchronous waves of one workgroup)
+        int wi = -1;
+        for (int i = 0; i < cfg.waves; i++) if (!W[i].finished && (wi < 0 || W[i].clock < W[wi].clock)) wi = i;
+        Wave& w = W[wi];
+        // ---- swap point: classify, park specular lanes, fill vacancies
+        int nD = 0, nS = 0, nE = 0;
+        for (auto& l : w.lane) { if (l.kind == 1) nD++; else if (l.kind == 2 || l.kind == 3) nS++; else if (l.kind == 0) nE++; }
+        // park specular lanes (if the queue has room; otherwise they stay and the iteration is mixed)
+        for (auto& l : w.lane)
+            if ((l.kind == 2 || l.kind == 3) && (int)sq.size() < cfg.sq_cap) { sq.push_back(l); l.kind = 0; nS--; nE++; }
+        st.max_sq = std::max(st.max_sq, (int)sq.size());
+        const int cam_avail = std::max(0, std::min(total_items, committed + cfg.window) - next_item);
+        bool batch = false;
+        if ((int)dq.size() >= nE) {
+            for (auto& l : w.lane) if (l.kind == 0 && !dq.empty()) { l = dq.front(); dq.erase(dq.begin()); }
+        } else if ((int)sq.size() + cam_avail >= cfg.s_batch_min && (int)dq.size() + nD <= cfg.dq_cap) {
+            // S-batch: spill the D lanes, take parked specular paths + fresh camera items
+            batch = true;
+            for (auto& l : w.lane) if (l.kind == 1) { dq.push_back(l); l.kind = 0; }
+            st.max_dq = std::max(st.max_dq, (int)dq.size());
+            for (auto& l : w.lane) {
+                if (l.kind != 0) continue;
+                if (!sq.empty()) { l = sq.front(); sq.erase(sq.begin()); }
+                else if (next_item < std::min(total_items, committed + cfg.window)) { l.item = next_item++; l.pos = 0; l.kind = 4; }
+            }
+        } else {
+            // not enough of anything for a uniform iteration: take what there is (tail of the workgroup's work)
+            for (auto& l : w.lane) if (l.kind == 0 && !dq.empty()) { l = dq.front(); dq.erase(dq.begin()); }
+            for (auto& l : w.lane) {
+                if (l.kind != 0) continue;
+                if (!sq.empty()) { l = sq.front(); sq.erase(sq.begin()); }
+                else if (next_item < std::min(total_items, committed + cfg.window)) { l.item = next_item++; l.pos = 0; l.kind = 4; }
+            }
+        }
+        st.max_window = std::max(st.max_window, next_item - committed);
+        // ---- one iteration: heads by kind, then intersect + prologue for every lane that continues
+        int n1 = 0, n2 = 0, n3 = 0, n4 = 0, nip = 0;
+        for (auto& l : w.lane) {
+            if (l.kind == 0) continue;
+            if (l.kind == 1) n1++; else if (l.kind == 2) n2++; else if (l.kind == 3) n3++; else n4++;
+        }
+        if (n1 + n2 + n3 + n4 == 0) {
+            if (next_item >= total_items && sq.empty() && dq.empty()) { w.finished = true; live_waves--; continue; }
+            // waiting for the window (or for another wave's parked paths): idle spin
+            w.clock += 50; st.cost += 0; st.stall_lane_iters += 64;
+            // guard: if every wave is idle and nothing can progress, bail out
+            bool any = false;
+            for (auto& o : W) for (auto& l : o.lane) if (l.kind) any = true;
+            if (!any && sq.empty() && dq.empty() && cam_avail == 0 && next_item < total_items) { fprintf(stderr, "deadlock\n"); exit(1); }
+            continue;
+        }
+        for (auto& l : w.lane) {
+            if (l.kind == 0) continue;
+            const auto& ev = path(l.item);
+            // head executed (material of event pos-1 for kinds 1..3, camera for 4); does the path go on to intersect?
+            bool cont = true;
+            if (l.kind != 4 && l.pos >= max_depth) cont = false;            // the material block of the last depth
+            if (!cont) { retire(l.item); l.kind = 0; st.n_samples++; continue; }
+            nip++;
+            if (l.pos >= (int)ev.size()) { retire(l.item); l.kind = 0; st.n_samples++; continue; }   // miss
+            int e = ev[l.pos++];
+            if (e == 0) { retire(l.item); l.kind = 0; st.n_samples++; }
+            else l.kind = e;
+        }
+        double cst = c.ov_iter + (batch ? c.ov_batch : 0) + (n1 ? c.d : 0) + (n3 ? c.g : 0) + (n2 ? c.m : 0) + (n4 ? c.cam : 0) + (nip ? c.ip : 0);
+        st.cost += cst;
+        st.useful += (n1 * c.d + n3 * c.g + n2 * c.m + n4 * c.cam + nip * c.ip) / 64.0;
+        st.iters += 1;
+        w.clock += cst;
+    }
+    st.cost += c.commit_item * total_items / 1.0 * (1.0);   // ordered commit (lanes of one wave, amortised)
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    int W = 900, H = 600, spp = 500, max_depth = 12, n_tiles = 32, pixels = 32;
+    unsigned seed = 1;
+    for (int i = 1; i + 1 < argc; i += 2) {
+        if (!strcmp(argv[i], "--spp")) spp = atoi(argv[i + 1]);
+        if (!strcmp(argv[i], "--tiles")) n_tiles = atoi(argv[i + 1]);
+        if (!strcmp(argv[i], "--seed")) seed = atoi(argv[i + 1]);
+    }
+    oracle::PT<TracePolicy> pt;
+    pt.planes = kPlanes; pt.nPlanes = 6; pt.spheres = kSpheres; pt.nSpheres = 3; pt.mathMode = oracle::MATH_LIBM;
+    std::mt19937 rng(seed);
+    std::vector<Tile> tiles(n_tiles);
+    double bounces = 0, nsamp = 0, hist[4] = {0, 0, 0, 0};
+    for (auto& t : tiles) {
+        int x0 = (rng() % (W / 8)) * 8, y0 = (rng() % (H / 4)) * 4;
+        t.samples.resize((size_t)pixels * spp);
+        for (int p = 0; p < pixels; p++)
+            for (int s = 0; s < spp; s++) {
+                auto& ev = t.samples[(size_t)p * spp + s];
+                g_events = &ev;
+                pt.sample(x0 + (p % 16) % 4 + 4 * (p / 16), y0 + (p % 16) / 4, W, H, s, max_depth);
+                bounces += ev.size(); nsamp++;
+                for (auto e : ev) hist[e]++;
+            }
+    }
+    printf("traced %d tiles x %d pixels x %d spp: %.2f hits/sample; events: RR-terminated %.3f diffuse %.3f mirror %.3f glass %.3f\n",
+           n_tiles, pixels, spp, bounces / nsamp, hist[0] / bounces, hist[1] / bounces, hist[2] / bounces, hist[3] / bounces);
+    Cost c;
+    Stats base;
+    for (auto& t : tiles) sim_rounds(t, pixels, spp, max_depth, c, base);
+    printf("%-58s cost/sample %7.1f  lanes %.3f  iters/64samples %.2f\n", "rounds (round 1 kernel)", base.cost / base.n_samples,
+           base.useful / base.cost, base.iters * 64.0 / base.n_samples);
+    struct Named { const char* name; RegroupCfg cfg; };
+    std::vector<Named> cfgs;
+    for (int waves : {1, 4, 8})
+        for (int win : {256, 512, 1024})
+            for (int bmin : {32, 48, 64}) {
+                RegroupCfg g; g.waves = waves; g.window = win; g.s_batch_min = bmin; g.dq_cap = 64 + 32 * waves; g.sq_cap = 64 + 32 * waves;
+                cfgs.push_back({"", g});
+            }
+    for (auto& n : cfgs) {
+        Stats s;
+        const int ppb = 4 * n.cfg.waves;   // pixels per workgroup: 4 per wave (as the rounds kernel at S = 16)
+        for (auto& t : tiles) for (int p0 = 0; p0 < pixels; p0 += ppb) sim_regroup(t, p0, ppb, spp, max_depth, c, n.cfg, s);
+        printf("regroup waves=%d window=%4d batch_min=%2d dq_cap=%3d sq_cap=%3d : cost/sample %7.1f (%.3fx)  lanes %.3f  maxDq %3d maxSq %3d maxWin %4d idle %.0f\n",
+               n.cfg.waves, n.cfg.window, n.cfg.s_batch_min, n.cfg.dq_cap, n.cfg.sq_cap, s.cost / s.n_samples,
+               (base.cost / base.n_samples) / (s.cost / s.n_samples), s.useful / s.cost, s.max_dq, s.max_sq, s.max_window, s.stall_lane_iters / 64);
+    }
+    return 0;
+}

@@ -12,7 +12,15 @@
 #include "mc_internal.h"
 #include "ds_arith.h"
 #include "mc_math.h"
+#ifndef MC_PT_FAST_CONTRACT
+#define MC_PT_FAST_CONTRACT 2
+#endif
+#if MC_PT_FAST_CONTRACT >= 1
 #pragma clang fp contract(fast)   // (reassociate(on) on top of this was tried: 697 vs 700 VALU instructions, not kept)
+#endif
+#if MC_PT_FAST_CONTRACT == 1
+#define MC_PT_DECISION_FP _Pragma("clang fp contract(off)")
+#endif
 #include "pathtrace_kernel.h"
 
 namespace mc {

@@ -30,6 +30,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "mc_internal.h"
 #include "ds_arith.h"
 #include "mc_math.h"
@@ -126,6 +128,14 @@ static __device__ unsigned long long g_region_lanes[16];
 #define MC_REGION(r) do { } while (0)
 #endif
 
+// Fast mode only: MC_PT_FAST_CONTRACT selects where the compiler may contract a*b+c (pathtrace_fast.hip):
+//   0 = nowhere (hardware transcendentals only), 1 = everywhere except the code that feeds the discrete decisions of a
+//   path (intersect(): nearest hit / det < 0 / denom > triEps; the glass block: total internal reflection, rnd.x < P),
+//   2 = everywhere.  The strict translation unit is built -ffp-contract=off and never defines MC_PT_DECISION_FP.
+#ifndef MC_PT_DECISION_FP
+#define MC_PT_DECISION_FP
+#endif
+
 constexpr float kEps = 1e-4f, kTriEps = 1e-7f, kInf = 1e20f;   // pathTracer.comp:103-105
 constexpr float kPi = 3.141592653589793f;                       // :102
 
@@ -202,6 +212,7 @@ __device__ __forceinline__ bool sphere_extended(const float* sp, float r2, v3 o,
 template <bool Fast, int NP, int NS, bool Slab, int Prec>
 __device__ __forceinline__ int intersect(const SceneArgs& sc, const float* __restrict__ obj, v3 o, v3 d, float& t_out,
                                          bool shadow_skip_planes = false) {
+    MC_PT_DECISION_FP
     constexpr bool LdsScene = NP < 0;
     const int np = NP >= 0 ? NP : (int)sc.n_planes;
     const int ns = NS >= 0 ? NS : (int)sc.n_spheres;
@@ -360,6 +371,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             ro = x;
             emissive = 1.0f;
         } else if (mat == 3) {                                            // :437 glass
+            MC_PT_DECISION_FP
             MC_REGION(6);   // glass
             bool into = (n.x == nl.x) && (n.y == nl.y) && (n.z == nl.z);  // :438
             const float nc = 1.0f, nt = 1.5f;
@@ -472,7 +484,10 @@ constexpr size_t kMaxSceneLdsBytes = 144u * 1024u;   // of the 160 KB per CU: 30
 template <bool Fast, int NP, int NS, bool Slab, int S, int Prec>
 inline int launch_one(const PTArgs& a, uint32_t tile_rows, hipStream_t s) {
     dim3 grid((a.W + block_w<S>() - 1u) / block_w<S>(), (tile_rows + block_h<S>() - 1u) / block_h<S>());
-    const size_t lds = scene_lds_bytes(a);
+    size_t lds = scene_lds_bytes(a);
+#ifdef MC_PT_DIAG_LDS_PAD   // diagnostic build only (make variants): pad the dynamic LDS to cap the resident waves per CU
+    if (const char* e = std::getenv("MC_PT_LDS_PAD")) lds += (size_t)std::atoi(e);
+#endif
     auto kern = pathtrace_kernel<Fast, NP, NS, Slab, S, Prec>;
     if (lds > 48u * 1024u) {   // beyond the default dynamic-LDS window: opt in (gfx950 has 160 KB per CU)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
