@@ -40,7 +40,7 @@ const float kSpheres[3 * 12] = {
 
 // ---- cost model: VALU wave-instructions per execution of a code block (DESIGN.md §3.3 region counters) ----
 struct Cost {
-    double ip = 284, d = 320, g = 93, m = 30, cam = 100;
+    double ip = 170, d = 190, g = 60, m = 20, cam = 70;   // fast kernel, measured (r02b): rounds = 12x170 + 11.9x190 + 10.4x60 + 8.5x20
     double ov_iter = 40;      // swap-point bookkeeping per scheduler iteration (ballots, prefix sums, LDS addressing)
     double ov_batch = 60;     // extra per S-batch (spill + reload addressing)
     double fold_round = 96;   // rounds kernel: ordered fold of 16 samples x 4 pixels
@@ -203,6 +203,56 @@ void sim_regroup(const Tile& t, int pix0, int pixels, int spp, int max_depth, co
     st.cost += c.commit_item * total_items / 1.0 * (1.0);   // ordered commit (lanes of one wave, amortised)
 }
 
+// ---------------------------------------------------------------- two path slots per lane, the parked one in LDS
+// Lane-private: no queues, no atomics — a lane exchanges its register path with the one in its own LDS slot
+// (ds_wrxchg_rtn_b32).  Every iteration the wave votes a mode: D (lanes that hold a diffuse-ready path run the diffuse head)
+// or S (lanes that hold a specular-pending path or can start a camera sample run those heads); intersect + prologue follows.
+struct TwoSlotCfg { int window = 256; int s_threshold = 40; int pixels = 4; };
+void sim_twoslot(const Tile& t, int pix0, int spp, int max_depth, const Cost& c, const TwoSlotCfg& cfg, Stats& st) {
+    const int pixels = cfg.pixels;
+    const int total_items = pixels * spp;
+    int next_item = 0, committed = 0;
+    std::vector<char> done(total_items, 0);
+    Rec A[64], B[64];
+    for (int l = 0; l < 64; l++) A[l].kind = B[l].kind = 0;
+    auto path = [&](int item) -> const std::vector<uint8_t>& { return t.samples[(size_t)(pix0 + item % pixels) * spp + item / pixels]; };
+    auto retire = [&](int item) { done[item] = 1; while (committed < total_items && done[committed]) committed++; st.n_samples++; };
+    for (;;) {
+        // empty slots take camera items (inside the window)
+        for (int l = 0; l < 64; l++)
+            for (Rec* r : {&A[l], &B[l]})
+                if (r->kind == 0 && next_item < std::min(total_items, committed + cfg.window)) { r->item = next_item++; r->pos = 0; r->kind = 4; }
+        st.max_window = std::max(st.max_window, next_item - committed);
+        int nD = 0, nS = 0, nAny = 0;
+        for (int l = 0; l < 64; l++) {
+            bool d = A[l].kind == 1 || B[l].kind == 1;
+            bool s2 = (A[l].kind >= 2) || (B[l].kind >= 2);
+            nD += d; nS += s2; nAny += (A[l].kind || B[l].kind);
+        }
+        if (!nAny) break;
+        const bool modeS = nS >= cfg.s_threshold || nD == 0 || (nS > nD);
+        int n1 = 0, n2 = 0, n3 = 0, n4 = 0, nip = 0;
+        for (int l = 0; l < 64; l++) {
+            // bring the path to run into A
+            auto runnable = [&](const Rec& r) { return modeS ? r.kind >= 2 : r.kind == 1; };
+            if (!runnable(A[l])) { if (runnable(B[l])) std::swap(A[l], B[l]); else continue; }
+            Rec& r = A[l];
+            if (r.kind == 1) n1++; else if (r.kind == 2) n2++; else if (r.kind == 3) n3++; else n4++;
+            const auto& ev = path(r.item);
+            if (r.kind != 4 && r.pos >= max_depth) { retire(r.item); r.kind = 0; continue; }
+            nip++;
+            if (r.pos >= (int)ev.size()) { retire(r.item); r.kind = 0; continue; }
+            int e = ev[r.pos++];
+            if (e == 0) { retire(r.item); r.kind = 0; } else r.kind = e;
+        }
+        double cst = c.ov_iter + (n1 ? c.d : 0) + (n3 ? c.g : 0) + (n2 ? c.m : 0) + (n4 ? c.cam : 0) + (nip ? c.ip : 0);
+        st.cost += cst;
+        st.useful += (n1 * c.d + n3 * c.g + n2 * c.m + n4 * c.cam + nip * c.ip) / 64.0;
+        st.iters += 1;
+    }
+    st.cost += c.commit_item * total_items;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -240,11 +290,12 @@ int main(int argc, char** argv) {
     struct Named { const char* name; RegroupCfg cfg; };
     std::vector<Named> cfgs;
     for (int waves : {1, 4, 8})
-        for (int win : {256, 512, 1024})
-            for (int bmin : {32, 48, 64}) {
-                RegroupCfg g; g.waves = waves; g.window = win; g.s_batch_min = bmin; g.dq_cap = 64 + 32 * waves; g.sq_cap = 64 + 32 * waves;
-                cfgs.push_back({"", g});
-            }
+        for (int win : {64 * waves, 128 * waves, 256 * waves})
+            for (int dqc : {64, 128})
+                for (int sqc : {64, 128}) {
+                    RegroupCfg g; g.waves = waves; g.window = win; g.s_batch_min = 48; g.dq_cap = dqc; g.sq_cap = sqc;
+                    cfgs.push_back({"", g});
+                }
     for (auto& n : cfgs) {
         Stats s;
         const int ppb = 4 * n.cfg.waves;   // pixels per workgroup: 4 per wave (as the rounds kernel at S = 16)
@@ -253,5 +304,15 @@ int main(int argc, char** argv) {
                n.cfg.waves, n.cfg.window, n.cfg.s_batch_min, n.cfg.dq_cap, n.cfg.sq_cap, s.cost / s.n_samples,
                (base.cost / base.n_samples) / (s.cost / s.n_samples), s.useful / s.cost, s.max_dq, s.max_sq, s.max_window, s.stall_lane_iters / 64);
     }
+    for (int ov : {10, 20})
+        for (int win : {64, 128, 256, 512})
+            for (int thr : {24, 32, 40, 48}) {
+                Cost c2 = c; c2.ov_iter = ov; c2.commit_item = 1.0;
+                TwoSlotCfg g; g.window = win; g.s_threshold = thr;
+                Stats s;
+                for (auto& t : tiles) for (int p0 = 0; p0 < pixels; p0 += g.pixels) sim_twoslot(t, p0, spp, max_depth, c2, g, s);
+                printf("twoslot ov=%2d window=%4d s_thr=%2d : cost/sample %7.1f (%.3fx)  lanes %.3f  iters/64 %.2f maxWin %4d\n", ov, win, thr,
+                       s.cost / s.n_samples, (base.cost / base.n_samples) / (s.cost / s.n_samples), s.useful / s.cost, s.iters * 64.0 / s.n_samples, s.max_window);
+            }
     return 0;
 }

@@ -37,6 +37,22 @@ int mc_context::note_launch(hipStream_t s) {
     MC_HIP_TRY(hipEventRecord(ev, s));
     return MC_OK;
 }
+int mc_context::ensure_status() {
+    if (status.ptr) return MC_OK;
+    int rc = status.reserve(256);
+    if (rc) return rc;
+    MC_HIP_TRY(hipMemset(status.ptr, 0, 256));
+    return MC_OK;
+}
+int mc_context::check_status() {
+    if (!status.ptr) return MC_OK;
+    uint32_t word = 0;
+    MC_HIP_TRY(hipMemcpy(&word, status.ptr, sizeof(word), hipMemcpyDeviceToHost));
+    if (!word) return MC_OK;
+    MC_HIP_TRY(hipMemset(status.ptr, 0, sizeof(word)));
+    mc::set_error_detail("path tracer scheduler tripped a loop bound (status " + std::to_string(word) + "): the image is incomplete");
+    return MC_ERR_HIP;
+}
 int mc_context::drain_launch_streams() {
     for (auto& e : launch_events) MC_HIP_TRY(hipEventSynchronize(e.second));
     return MC_OK;
@@ -207,6 +223,7 @@ int mc_context_destroy(mc_context* ctx) {
     ctx->scratch_iters.release();
     ctx->scratch_u8.release();
     ctx->scene_buf.release();
+    ctx->status.release();
     delete ctx;
     return MC_OK;
 }
@@ -226,7 +243,7 @@ int mc_context_synchronize(mc_context* ctx) {
     if (!ctx) return MC_ERR_INVALID_ARGUMENT;
     MC_HIP_TRY(hipSetDevice(ctx->device));
     MC_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return MC_OK;
+    return ctx->check_status();
 }
 
 int mc_pathtrace_scene_class(const float* planes, uint32_t n_planes, const float* spheres, uint32_t n_spheres,
@@ -336,7 +353,7 @@ int mc_pathtrace_render(mc_context* ctx, const mc_pathtrace_params* p, const flo
     if (rc) return rc;
     MC_HIP_TRY(hipMemcpyAsync(out_rgba_f32, ctx->scratch_rgba.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
     MC_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return MC_OK;
+    return ctx->check_status();
 }
 
 // ---- post-process -----------------------------------------------------------------------------------

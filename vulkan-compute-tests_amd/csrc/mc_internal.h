@@ -54,6 +54,11 @@ struct mc_context {
     std::vector<std::pair<hipStream_t, hipEvent_t>> launch_events;
     int note_launch(hipStream_t s);
     int drain_launch_streams();
+    // Device status word: a kernel whose scheduler trips one of its loop bounds ORs a bit in instead of spinning
+    // (pathtrace_regroup.h).  Checked — and cleared — by the blocking entry points and mc_context_synchronize().
+    mc::DeviceBuffer status;
+    int ensure_status();
+    int check_status();   // call after the stream is idle: MC_OK, or MC_ERR_HIP with a detail message
 };
 
 namespace mc {

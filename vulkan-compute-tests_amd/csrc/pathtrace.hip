@@ -93,6 +93,13 @@ void set_camera(PTArgs& a) {
     a.lc = h_add(a.cam_o, h_muls(a.cam_d, 0.035f));
 }
 
+// The lane-regrouping scheduler pays off once a workgroup (16 pixels x the call's samples) has enough items to keep its
+// 256 lanes and its queues busy; below that the round-synchronous kernels' start-up and tail are shorter.
+bool regroup_by_default(uint32_t n_samples) {
+    if (const char* e = std::getenv("MC_PT_REGROUP")) return e[0] == '1' && n_samples >= 1u;   // experiments
+    return false;   // opt-in (MC_PT_KERNEL_REGROUP) until measured
+}
+
 // Sample-parallel width: enough waves to keep 256 CUs x ~28 wave slots busy with a short tail.
 int choose_S(uint64_t pixels, uint32_t samples) {
     const uint64_t target_waves = 65536;
@@ -183,7 +190,24 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
     if (S == 0) S = choose_S((uint64_t)rows * p->width, p->sample_end - p->sample_begin);
     if (S != 1 && S != 4 && S != 16) return MC_ERR_INVALID_ARGUMENT;
     if (prec != 0 && S == 4) S = (p->sample_end - p->sample_begin) >= 16 ? 16 : 1;   // precision variants exist for S = 1, 16
-    const int variant = slab ? 1 : 0;
+    int variant = slab ? 1 : 0;
+    // Lane-regrouping scheduler (pathtrace_regroup.h): slab scenes whose materials are all 1..3 (any other code makes the
+    // shader re-trace an unchanged ray, which only the round-synchronous loop reproduces) within its packed-field limits.
+    bool regroup_ok = slab && prec == 0 && p->max_depth <= 63u && p->width < 65536u && p->height <= 65536u &&
+                      (p->sample_end - p->sample_begin) < (1u << 20);
+    for (uint32_t i = 0; regroup_ok && i < n_planes + n_spheres; i++) {
+        const float m = floorf((i < n_planes ? planes[12 * i + 11] : spheres[12 * (i - n_planes) + 11]) + 0.5f);
+        if (!(m == 1.0f || m == 2.0f || m == 3.0f)) regroup_ok = false;
+    }
+    const bool forced_s = ((p->flags >> 8) & 0xffu) != 0u;
+    if (regroup_ok && !(p->flags & MC_PT_KERNEL_ROUNDS) && !forced_s &&
+        ((p->flags & MC_PT_KERNEL_REGROUP) || regroup_by_default(p->sample_end - p->sample_begin)))
+        variant = 2;
+    if (variant == 2) {
+        int rc = ctx->ensure_status();
+        if (rc) return rc;
+        a.status = (uint32_t*)ctx->status.ptr;
+    }
     auto launch = [&](const PTArgs& args, int width) {
         return p->math_mode == MC_PT_MATH_FAST ? pt::launch_fast(args, variant, width, prec, rows, s)
                                                : pt::launch_strict(args, variant, width, prec, rows, s);
@@ -195,7 +219,10 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
     const uint32_t n_samples = p->sample_end - p->sample_begin;
     const bool auto_width = ((p->flags >> 8) & 0xffu) == 0u;
     const uint32_t rest = n_samples % (uint32_t)S;
-    if (auto_width && prec == 0 && S > 1 && rest != 0u && n_samples > (uint32_t)S) {
+    if (variant == 2) {
+        int rc = launch(a, 16);
+        if (rc) return rc;
+    } else if (auto_width && prec == 0 && S > 1 && rest != 0u && n_samples > (uint32_t)S) {
         PTArgs head = a, tail = a;
         head.sample_end = tail.sample_begin = a.sample_end - rest;
         int rc = launch(head, S);

@@ -22,10 +22,12 @@
 #define MC_PT_DECISION_FP _Pragma("clang fp contract(off)")
 #endif
 #include "pathtrace_kernel.h"
+#include "pathtrace_regroup.h"
 
 namespace mc {
 namespace pt {
 int launch_fast(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s) {
+    if (variant == 2) return launch_regroup<true, 4>(a, tile_rows, s);
     return launch_impl<true>(a, variant, S, prec, tile_rows, s);
 }
 }  // namespace pt

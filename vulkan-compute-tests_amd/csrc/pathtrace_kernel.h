@@ -76,6 +76,7 @@ struct PTArgs {
     // camera basis (pathTracer.comp:352-353,360), evaluated once on the host with the same IEEE ops
     v3 cam_o, cam_d, cx, cy, lc;
     float4* __restrict__ out;   // tile-local storage rows
+    uint32_t* status;           // context-owned device word: a kernel ORs a bit in when a scheduler bound trips (else untouched)
     SceneArgs scene;
 };
 
@@ -473,6 +474,7 @@ __global__ void __launch_bounds__(256) pathtrace_kernel(PTArgs a) {
 // variant: 0 = generic (run-time object counts), 1 = slab-specialised 6 planes + 3 spheres.
 // prec: 0 = fp32 sphere test (the reference's default build); 1/2/3 = native fp64 / DS / DF64 branch (generic kernel,
 // S in {1,16} only).
+// variant 2 = the lane-regrouping scheduler (pathtrace_regroup.h; slab scenes, S is ignored).
 int launch_fast(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s);
 int launch_strict(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s);
 

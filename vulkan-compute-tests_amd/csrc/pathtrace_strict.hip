@@ -1,10 +1,12 @@
 // Instantiates the MC_PT_MATH_STRICT path tracer kernels (IEEE divide/sqrt + mc_math sin/cos/pow:
 // bit-identical to the CPU oracle).  Split from the fast instantiations so both compile in parallel.
 #include "pathtrace_kernel.h"
+#include "pathtrace_regroup.h"
 
 namespace mc {
 namespace pt {
 int launch_strict(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s) {
+    if (variant == 2) return launch_regroup<false, 4>(a, tile_rows, s);
     return launch_impl<false>(a, variant, S, prec, tile_rows, s);
 }
 }  // namespace pt
