@@ -105,9 +105,9 @@ enum {
 /* mc_pathtrace_params.flags — diagnostics; every combination produces bit-identical buffers */
 enum {
     MC_PT_GENERIC_KERNEL = 1u << 0, /* never use the axis-aligned-slab specialisation of the plane test */
-    MC_PT_KERNEL_REGROUP = 1u << 1, /* force the lane-regrouping scheduler (csrc/pathtrace_regroup.h) where it applies: */
-                                    /* slab scene, materials 1..3, max_depth <= 63, W,H < 65536, < 2^20 samples per call */
-    MC_PT_KERNEL_ROUNDS = 1u << 2   /* force the round-synchronous kernels (csrc/pathtrace_kernel.h)                    */
+    MC_PT_KERNEL_REGROUP = 1u << 1  /* DIAGNOSTIC library only (make regroup -> lib/libmc_compute_regroup.so): the lane-     */
+                                    /* regrouping scheduler (csrc/pathtrace_regroup.h), measured slower than the default     */
+                                    /* kernels; the shipped library returns MC_ERR_UNSUPPORTED for this flag      */
 };
 #define MC_PT_FORCE_S(s) ((uint32_t)(s) << 8) /* force the sample-parallel width: 1, 4 or 16 (0 = automatic) */
 /* Sphere-test precision branch of pathTracer.comp:132-256.  The reference compiles every variant OUT

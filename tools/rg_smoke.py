@@ -2,7 +2,9 @@
 starts (a hang shows where), then K2 timings.  Run under `timeout`."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("MC_LIB_PATH", os.path.join(ROOT, "vulkan-compute-tests_amd", "lib", "libmc_compute_regroup.so"))   # diagnostic library
 import __graft_entry__ as entry
 B = entry.load_package().bindings
 O = entry.load_oracle()
@@ -24,7 +26,7 @@ if "--time" in sys.argv:
     W, H, spp = 900, 600, 500
     buf = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     for mode, name in ((B.PT_MATH_FAST, "fast"), (B.PT_MATH_STRICT, "strict")):
-        for flags, fname in ((B.PT_KERNEL_ROUNDS, "rounds"), (B.PT_KERNEL_REGROUP, "regroup")):
+        for flags, fname in ((0, "rounds"), (B.PT_KERNEL_REGROUP, "regroup")):
             p = B.pathtrace_params(W, H, spp, math_mode=mode, flags=flags)
             for _ in range(2): ctx.pathtrace_device(p, buf.data_ptr(), stream=s)
             torch.cuda.synchronize()

@@ -93,13 +93,6 @@ void set_camera(PTArgs& a) {
     a.lc = h_add(a.cam_o, h_muls(a.cam_d, 0.035f));
 }
 
-// The lane-regrouping scheduler pays off once a workgroup (16 pixels x the call's samples) has enough items to keep its
-// 256 lanes and its queues busy; below that the round-synchronous kernels' start-up and tail are shorter.
-bool regroup_by_default(uint32_t n_samples) {
-    if (const char* e = std::getenv("MC_PT_REGROUP")) return e[0] == '1' && n_samples >= 1u;   // experiments
-    return false;   // opt-in (MC_PT_KERNEL_REGROUP) until measured
-}
-
 // Sample-parallel width: enough waves to keep 256 CUs x ~28 wave slots busy with a short tail.
 int choose_S(uint64_t pixels, uint32_t samples) {
     const uint64_t target_waves = 65536;
@@ -199,10 +192,17 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
         const float m = floorf((i < n_planes ? planes[12 * i + 11] : spheres[12 * (i - n_planes) + 11]) + 0.5f);
         if (!(m == 1.0f || m == 2.0f || m == 3.0f)) regroup_ok = false;
     }
-    const bool forced_s = ((p->flags >> 8) & 0xffu) != 0u;
-    if (regroup_ok && !(p->flags & MC_PT_KERNEL_ROUNDS) && !forced_s &&
-        ((p->flags & MC_PT_KERNEL_REGROUP) || regroup_by_default(p->sample_end - p->sample_begin)))
-        variant = 2;
+    // Never the default: measured slower than the round-synchronous kernels.  The kernel is compiled only
+    // into the diagnostic library (make regroup, -DMC_PT_WITH_REGROUP); the shipped library answers MC_ERR_UNSUPPORTED.
+    if (p->flags & MC_PT_KERNEL_REGROUP) {
+#ifdef MC_PT_WITH_REGROUP
+        if (regroup_ok) variant = 2;   // outside its limits the request falls back to the round-synchronous kernels
+#else
+        (void)regroup_ok;
+        set_error_detail("MC_PT_KERNEL_REGROUP: the lane-regrouping kernel is only built into lib/libmc_compute_regroup.so (make regroup)");
+        return MC_ERR_UNSUPPORTED;
+#endif
+    }
     if (variant == 2) {
         int rc = ctx->ensure_status();
         if (rc) return rc;

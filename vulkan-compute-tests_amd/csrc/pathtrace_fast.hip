@@ -22,12 +22,17 @@
 #define MC_PT_DECISION_FP _Pragma("clang fp contract(off)")
 #endif
 #include "pathtrace_kernel.h"
+#ifdef MC_PT_WITH_REGROUP   // diagnostic library only (make regroup): the lane-regrouping scheduler, DESIGN.md §3.3
 #include "pathtrace_regroup.h"
+#endif
 
 namespace mc {
 namespace pt {
 int launch_fast(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s) {
+#ifdef MC_PT_WITH_REGROUP
     if (variant == 2) return launch_regroup<true, 4>(a, tile_rows, s);
+#endif
+    if (variant == 2) return MC_ERR_UNSUPPORTED;
     return launch_impl<true>(a, variant, S, prec, tile_rows, s);
 }
 }  // namespace pt

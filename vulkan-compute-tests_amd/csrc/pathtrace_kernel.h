@@ -117,6 +117,10 @@ __device__ __forceinline__ v3 rand01(uint32_t x, uint32_t y, uint32_t z) {
 #ifdef MC_PT_REGION_STATS
 static __device__ unsigned long long g_region_exec[16];
 static __device__ unsigned long long g_region_lanes[16];
+#ifdef MC_PT_REGION_TIME
+#define MC_REGION(r) do { } while (0)
+#define MC_ACCUM(r, value) do { } while (0)
+#else
 #define MC_REGION(r)                                                                            \
     do {                                                                                        \
         unsigned long long m_ = __ballot(1);                                                    \
@@ -125,8 +129,49 @@ static __device__ unsigned long long g_region_lanes[16];
             atomicAdd(&g_region_lanes[r], (unsigned long long)__popcll(m_));                    \
         }                                                                                       \
     } while (0)
+// accumulates a wave-uniform value (the "lanes" column then holds its sum, "exec" the number of observations)
+#define MC_ACCUM(r, value)                                                                      \
+    do {                                                                                        \
+        unsigned long long m_ = __ballot(1);                                                    \
+        if ((int)__lane_id() == __ffsll((long long)m_) - 1) {                                   \
+            atomicAdd(&g_region_exec[r], 1ull);                                                 \
+            atomicAdd(&g_region_lanes[r], (unsigned long long)(value));                         \
+        }                                                                                       \
+    } while (0)
+#endif
+// MC_PT_REGION_TIME (with MC_PT_REGION_STATS): wall cycles of a wave between two marks, summed per region
+// Accumulated in (scalar) registers and flushed once per wave (MC_TIME_FLUSH), so the marks do not stretch the code
+// between them with global atomics.
+#ifdef MC_PT_REGION_TIME
+#define MC_TIME_INIT unsigned long long mc_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned int mc_cnt_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long mc_t_ = 0
+#define MC_TIME_DECL mc_t_ = __builtin_amdgcn_s_memtime()
+#define MC_TIME_MARK(r)                                                                         \
+    do {                                                                                        \
+        const unsigned long long n_ = __builtin_amdgcn_s_memtime();                             \
+        mc_acc_[r] += n_ - mc_t_; mc_cnt_[r]++;                                                 \
+        mc_t_ = n_;                                                                             \
+    } while (0)
+#define MC_TIME_COUNT(r, v) do { mc_acc_[r] += (unsigned long long)(v); mc_cnt_[r]++; } while (0)   /* register-held counter */
+#define MC_TIME_FLUSH                                                                           \
+    do {                                                                                        \
+        if (__lane_id() == 0u)                                                                  \
+            for (int r_ = 0; r_ < 12; r_++) { atomicAdd(&g_region_exec[r_], (unsigned long long)mc_cnt_[r_]); atomicAdd(&g_region_lanes[r_], mc_acc_[r_]); } \
+    } while (0)
+#else
+#define MC_TIME_INIT do { } while (0)
+#define MC_TIME_DECL do { } while (0)
+#define MC_TIME_MARK(r) do { } while (0)
+#define MC_TIME_COUNT(r, v) do { } while (0)
+#define MC_TIME_FLUSH do { } while (0)
+#endif
 #else
 #define MC_REGION(r) do { } while (0)
+#define MC_ACCUM(r, value) do { } while (0)
+#define MC_TIME_INIT do { } while (0)
+#define MC_TIME_DECL do { } while (0)
+#define MC_TIME_MARK(r) do { } while (0)
+#define MC_TIME_COUNT(r, v) do { } while (0)
+#define MC_TIME_FLUSH do { } while (0)
 #endif
 
 // Fast mode only: MC_PT_FAST_CONTRACT selects where the compiler may contract a*b+c (pathtrace_fast.hip):
@@ -197,6 +242,75 @@ __device__ __forceinline__ bool sphere_extended(const float* sp, float r2, v3 o,
         if (!(dd > kEps)) { dd = bPlus; if (!(dd > kEps)) dd = kInf; }
         return true;
     }
+}
+
+// ---- hot constants of the slab scene, held in VECTOR registers ----------------------------------------------------------
+// profiles/r02_valu_microbench2.txt: on gfx950 a v_add/v_sub/v_mul/v_fmac whose operand is an SGPR issues in ~4.1 cycles, with
+// VGPR or literal operands in ~2.3-2.5.  The compiler keeps uniform values (kernel arguments, hoisted literals such as 1e20f)
+// in SGPRs, so every `centre - o`, `w - o[a]`, `det + r2` of the intersection code paid the slow form.  The 6 + 3 object
+// scene fits in 25 registers per lane; the slab kernels have room for them (36 of the 64 VGPRs of full occupancy in use).
+// The asm is only an opaque move: the compiler cannot fold the value back into an SGPR operand.  Same values, same results.
+__device__ __forceinline__ float to_vgpr(float uniform) {
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform));
+    return v;
+}
+struct HotSlab {
+    float W_pos[3], W_negm[3];   // w of the +e_a plane; MINUS w of the -e_a plane (see intersect_slab)
+    float c[3][3], r2[3];        // sphere centres, radius^2 (the fp32 product of pathTracer.comp:318)
+    float eps, tri_eps, inf;     // kEps, kTriEps, kInf
+    // InVgpr = false leaves the values to the compiler (SGPR operands): for kernels without the register headroom.
+    template <bool InVgpr = true> __device__ __forceinline__ void load(const SceneArgs& sc) {
+        auto put = [](float u) { return InVgpr ? to_vgpr(u) : u; };
+#pragma unroll
+        for (int a = 0; a < 3; a++) { W_pos[a] = put(sc.slab_w_pos[a]); W_negm[a] = put(-sc.slab_w_neg[a]); }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) c[i][k] = put(sc.obj[12 * (6 + i) + k]);
+            r2[i] = put(sc.r2[i]);
+        }
+        eps = put(1e-4f); tri_eps = put(1e-7f); inf = put(1e20f);
+    }
+};
+
+// intersect() for the slab scene (6 axis-aligned planes in canonical order + 3 spheres), constants in VGPRs.
+// Plane of axis a facing the ray: "pos" (normal +e_a) iff d[a] > 0, else "neg".  The reference quotient of the neg plane,
+// (w_neg + o[a]) / |d[a]|, equals ((-w_neg) - o[a]) / d[a] bit for bit: negation is exact, (-x) - y = -(x + y) under
+// round-to-nearest, and (-n) / (-d) = n / d (IEEE divide; v_rcp_f32 is odd, tested).  So both cases are
+// (W - o[a]) / d[a] with W = pos ? w_pos : -w_neg: one select and one subtraction instead of two additions and a select.
+template <bool Fast>
+__device__ __forceinline__ int intersect_slab(const HotSlab& h, v3 o, v3 d, float& t_out, bool shadow_skip_planes) {
+    MC_PT_DECISION_FP
+    float t = h.inf;
+    int id = -1;
+    if (!shadow_skip_planes) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float da = comp(d, a), oa = comp(o, a);
+            const bool pos = da > 0.0f;
+            const float W = pos ? h.W_pos[a] : h.W_negm[a];
+            const float dd = dm::fdiv<Fast>(W - oa, da);
+            if (__builtin_fabsf(da) > h.tri_eps && dd < t) { t = dd; id = pos ? 2 * a + 1 : 2 * a; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        v3 oc = v3{h.c[i][0], h.c[i][1], h.c[i][2]} - o;                     // :317
+        float b = dot(oc, d);                                                // :318
+        float det = (b * b - dot(oc, oc)) + h.r2[i];
+        if (!(det < 0.0f)) {                                                 // :319
+            float sq = dm::fsqrt<Fast>(det);
+            float dd = b - sq;                                               // :322,324
+            if (dd <= h.eps) {                                               // :325
+                dd = b + sq;                                                 // :323,326
+                if (dd <= h.eps) dd = h.inf;                                 // :327
+            }
+            if (dd < t) { t = dd; id = 6 + i; }                              // :333
+        }
+    }
+    t_out = t;
+    return (t < h.inf) ? id : -1;                                            // :336
 }
 
 // intersect — pathTracer.comp:112-131 + :316-341.  Returns the hit object id (planes 0..NP-1, spheres
@@ -284,7 +398,8 @@ __device__ __forceinline__ int intersect(const SceneArgs& sc, const float* __res
 // One sample: returns accrad (pathTracer.comp:356-449).
 template <bool Fast, int NP, int NS, bool Slab, int Prec>
 __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restrict__ lds_obj,
-                                           const uint32_t* __restrict__ lds_emissive, uint32_t gx, uint32_t gy, uint32_t samp) {
+                                           const uint32_t* __restrict__ lds_emissive, const HotSlab& hot, uint32_t gx, uint32_t gy,
+                                           uint32_t samp) {
     const SceneArgs& sc = a.scene;
     constexpr bool LdsScene = NP < 0;
     const float* __restrict__ uobj = LdsScene ? lds_obj : sc.obj;   // records read with wave-uniform indices
@@ -307,7 +422,9 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
     for (uint32_t depth = 0; depth < a.max_depth; depth++) {              // :367
         MC_REGION(1);   // primary intersect
         float t;
-        int id = intersect<Fast, NP, NS, Slab, Prec>(sc, uobj, ro, rd, t);
+        int id;
+        if constexpr (Slab) id = intersect_slab<Fast>(hot, ro, rd, t, false);
+        else id = intersect<Fast, NP, NS, Slab, Prec>(sc, uobj, ro, rd, t);
         if (id < 0) break;   // :369 `continue` with an unchanged ray misses again at every later depth: no effect
         MC_REGION(2);   // bounce prologue
         v3 x = ro + rd * t;                                               // :374 (o + t*d: fp32 mul is commutative)
@@ -349,7 +466,9 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 dm::sincos_angle<Fast>(phi, rnd.y, sphi, cphi);
                 v3 l = normalize<Fast>(((su * cphi) * sin_a + (sv * sphi) * sin_a) + sw * cos_a);   // :413
                 float tne;
-                int idne = intersect<Fast, NP, NS, Slab, Prec>(sc, uobj, x, l, tne, Slab && sc.nee_skip_planes != 0u);  // :420 shadow ray
+                int idne;                                                 // :420 shadow ray
+                if constexpr (Slab) idne = intersect_slab<Fast>(hot, x, l, tne, sc.nee_skip_planes != 0u);
+                else idne = intersect<Fast, NP, NS, Slab, Prec>(sc, uobj, x, l, tne, false);
                 if (idne == np + i) {
                     MC_REGION(4);   // shadow ray reached the light
                     float omega = (2.0f * kPi) * (1.0f - cos_a_max);      // :421
@@ -416,7 +535,7 @@ template <int S> constexpr uint32_t block_w() { return 2u * WaveTile<S>::w; }
 template <int S> constexpr uint32_t block_h() { return 2u * WaveTile<S>::h; }
 
 template <bool Fast, int NP, int NS, bool Slab, int S, int Prec>
-__global__ void __launch_bounds__(256) pathtrace_kernel(PTArgs a) {
+__global__ void __launch_bounds__(256, 6) pathtrace_kernel(PTArgs a) {
     // dynamic LDS (no static __shared__ in front: the base stays 16-B aligned): [records | emissive list]
     extern __shared__ float lds_dyn[];
     float* lds_obj = lds_dyn;
@@ -442,12 +561,14 @@ __global__ void __launch_bounds__(256) pathtrace_kernel(PTArgs a) {
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (valid && a.sample_begin > 0) acc = a.out[idx];   // progressive continuation (samps.x protocol); s==0 resets (:451)
     const float fspp = (float)a.spp;
+    HotSlab hot;
+    if constexpr (Slab) hot.load(a.scene);
     const uint32_t group_base = lane - j;           // first lane of this pixel's group
     for (uint32_t base = a.sample_begin; base < a.sample_end; base += (uint32_t)S) {
         const uint32_t s = base + j;
         v3 q{0.0f, 0.0f, 0.0f};
         if (valid && s < a.sample_end) {
-            v3 rad = trace_sample<Fast, NP, NS, Slab, Prec>(a, lds_obj, lds_emissive, gx, gy, s);
+            v3 rad = trace_sample<Fast, NP, NS, Slab, Prec>(a, lds_obj, lds_emissive, hot, gx, gy, s);
             q = divs<Fast>(rad, fspp);                                          // :452 accrad / samps.y
         }
         // fold the round's S samples into the accumulator in sample order (every lane of the group

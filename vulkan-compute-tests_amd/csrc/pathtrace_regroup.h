@@ -40,19 +40,18 @@ enum : uint32_t { RG_EMPTY = 0, RG_D = 1, RG_M = 2, RG_G = 3, RG_CAM = 4 };
 
 template <int NW> struct RgGeom;
 template <> struct RgGeom<4> {
-    static constexpr uint32_t PB = 16, PW = 4, PH = 4;        // pixels per workgroup
-    static constexpr uint32_t DQ = 64, SQ = 64, WIN = 512;    // FIFO capacities (records), reorder window (items)
-};
-template <> struct RgGeom<1> {
-    static constexpr uint32_t PB = 4, PW = 2, PH = 2;
-    static constexpr uint32_t DQ = 64, SQ = 64, WIN = 256;
+    static constexpr uint32_t PB = 16, PW = 4, PH = 4;   // pixels per workgroup
+    static constexpr uint32_t QCAP = 64;                 // capacity of each FIFO (records)
+    static constexpr uint32_t WIN = 1024;                // reorder window (items): ~4 rounds of the 256 lanes; multi-bounce
+                                                         // specular paths wait for a batch per bounce and hold the window back
 };
 constexpr uint32_t kRgBatchMin = 48;          // parked specular + available camera items that justify a batch
 constexpr uint32_t kRgSpinLimit = 1u << 22;   // bound of every wait loop (a healthy wait is a few hundred cycles)
 constexpr uint32_t kRgMaxDepth = 63;          // meta packs the depth into 6 bits
 constexpr uint32_t kRgMaxItems = 1u << 24;    // ... and the item index into 24
+constexpr int kRgFields = 19;                 // dwords per record
 
-// meta: bits 0-23 item (sample-major: item = (samp - sample_begin) * PB + pixel), bits 24-29 depth, bit 30-31 unused
+// meta: bits 0-23 item (sample-major: item = (samp - sample_begin) * PB + pixel), bits 24-29 depth
 __device__ __forceinline__ uint32_t rg_item(uint32_t meta) { return meta & 0xffffffu; }
 __device__ __forceinline__ uint32_t rg_depth(uint32_t meta) { return (meta >> 24) & 63u; }
 
@@ -60,15 +59,19 @@ template <int NW>
 struct RgShared {
     using G = RgGeom<NW>;
     float obj[(6 + 3) * 12];                   // scene records for the per-lane material fetch
-    uint32_t dq_head, dq_tail, sq_head, sq_tail;
+    // The four ticket counters of the two FIFOs in ONE word, so that a wave makes all its reservations of a swap point with a
+    // single compare-and-swap: bits 0-15 dq_head, 16-31 dq_tail, 32-47 sq_head, 48-63 sq_tail (tickets wrap at 2^16).
+    unsigned long long qctl;
     uint32_t next_item, committed, commit_lock, waves_done;
     uint32_t pixkey[G::PB];                    // gx | gy << 16 of the workgroup's pixels, 0xffffffff outside the image
     float4 acc[G::PB];                         // xyz accumulator, w = bits of the number of samples folded in so far
-    uint32_t dq_seq[G::DQ], sq_seq[G::SQ];
-    float4 dq_rec[4][G::DQ];                   // (x, rnd.x) (nl, rnd.y) (accmat, meta) (accrad, pixkey)
-    float4 sq_rec[5][G::SQ];                   // (x, rnd.x) (rd, kind) (accmat, meta) (accrad, pixkey) (n, -)
-    float4 ring[G::WIN];                       // xyz = accrad / spp of a finished sample awaiting its turn; w = bits of
-                                               // item + 1, written (as its own dword) after xyz is in place
+    uint32_t seq[2 * G::QCAP];                 // per slot: DQ = slots 0..QCAP-1, SQ = slots QCAP..2*QCAP-1
+    float rec[kRgFields][2 * G::QCAP];         // records, one dword array per field (conflict-free ds_read/write_b32, no
+                                               // register-tuple constraints): X.xyz V.xyz N.xyz accmat.xyz accrad.xyz rx ry meta
+                                               // meta | kind << 30, pixkey
+    float ring[3][G::WIN];                     // accrad of finished samples awaiting their turn (divided by spp at the fold)
+    uint8_t ring_tag[G::WIN];                  // low byte of (lap + 1), lap = item / WIN, once the three floats are in place
+                                               // (a slot's previous occupant left `lap`, so a stale entry never matches)
 };
 
 __device__ __forceinline__ uint32_t rg_ld(const uint32_t* p) {
@@ -79,58 +82,19 @@ __device__ __forceinline__ void rg_st(uint32_t* p, uint32_t v) {
 }
 __device__ __forceinline__ void rg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 __device__ __forceinline__ void rg_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+// Order between this wave's own DS operations: they execute in issue order, so only the compiler has to keep them in place.
+__device__ __forceinline__ void rg_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 __device__ __forceinline__ uint32_t rg_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ unsigned long long rg_uniform64(unsigned long long v) {
+    return (unsigned long long)rg_uniform((uint32_t)v) | ((unsigned long long)rg_uniform((uint32_t)(v >> 32)) << 32);
+}
 __device__ __forceinline__ uint32_t rg_rank(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// Reserves n tickets for a push (lane 0 decides; wave-uniform result): the base ticket, or 0xffffffff when the FIFO cannot
-// take n more records.  `head` only grows, so a stale value is conservative.
-__device__ __forceinline__ uint32_t rg_reserve_push(uint32_t* tail, const uint32_t* head, uint32_t n, uint32_t cap, uint32_t lane) {
-    uint32_t base = 0xffffffffu;
-    if (lane == 0) {
-        uint32_t t = rg_ld(tail);
-        for (int k = 0; k < 64; k++) {
-            const uint32_t h = rg_ld(head);
-            if (t - h + n > cap) break;
-            const uint32_t o = atomicCAS(tail, t, t + n);
-            if (o == t) { base = t; break; }
-            t = o;
-        }
-    }
-    return rg_uniform(base);
-}
-// Reserves up to n tickets for a pop: returns the base ticket and the number granted (0 when the FIFO is empty).
-__device__ __forceinline__ uint32_t rg_reserve_pop(uint32_t* head, const uint32_t* tail, uint32_t n, uint32_t lane, uint32_t& granted) {
-    uint32_t base = 0, got = 0;
-    if (lane == 0) {
-        uint32_t h = rg_ld(head);
-        for (int k = 0; k < 64; k++) {
-            const uint32_t t = rg_ld(tail);
-            const uint32_t avail = t - h;                    // tail is read after head: never behind it
-            const uint32_t g = avail < n ? avail : n;
-            if (g == 0u || avail > 0x7fffffffu) break;
-            const uint32_t o = atomicCAS(head, h, h + g);
-            if (o == h) { base = h; got = g; break; }
-            h = o;
-        }
-    }
-    granted = rg_uniform(got);
-    return rg_uniform(base);
-}
-// Waits (bounded) until the sequence word of this lane's slot shows `expect`; inactive lanes pass `on = false`.
-__device__ __forceinline__ bool rg_wait_seq(const uint32_t* seq, uint32_t expect, bool on) {
-    for (uint32_t spins = 0; spins < kRgSpinLimit; spins++) {
-        const bool ready = !on || rg_ld(seq) == expect;
-        if (__ballot(!ready) == 0ull) return true;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    return false;
-}
-
 // State of the path a lane holds between two scheduler iterations (= one FIFO record).
 struct RgPath {
-    v3 X;          // RG_D / RG_M / RG_G: the hit point x (the next ray origin); RG_CAM: unused
+    v3 X;          // RG_D / RG_M / RG_G: the hit point x (the next ray origin)
     v3 V;          // RG_D: nl; RG_M / RG_G: the incoming ray direction
     v3 N;          // RG_M / RG_G: the surface normal n
     v3 accmat, accrad;
@@ -142,6 +106,7 @@ template <bool Fast, int NW>
 __global__ void __launch_bounds__(64 * NW, 6) pathtrace_regroup_kernel(PTArgs a) {
     using G = RgGeom<NW>;
     constexpr int NP = 6, NS = 3;
+    constexpr uint32_t Q = G::QCAP;
     __shared__ RgShared<NW> sh;
     const uint32_t lane = threadIdx.x & 63u;
     const SceneArgs& sc = a.scene;
@@ -150,11 +115,10 @@ __global__ void __launch_bounds__(64 * NW, 6) pathtrace_regroup_kernel(PTArgs a)
 
     // ---- start-up (the only barrier) ----
     for (uint32_t i = threadIdx.x; i < (NP + NS) * 12u; i += 64u * NW) sh.obj[i] = sc.obj[i];
-    for (uint32_t i = threadIdx.x; i < G::DQ; i += 64u * NW) sh.dq_seq[i] = i;
-    for (uint32_t i = threadIdx.x; i < G::SQ; i += 64u * NW) sh.sq_seq[i] = i;
-    for (uint32_t i = threadIdx.x; i < G::WIN; i += 64u * NW) sh.ring[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // tag 0: empty
+    for (uint32_t i = threadIdx.x; i < 2u * Q; i += 64u * NW) sh.seq[i] = i & (Q - 1u);   // slot s is first written by ticket s
+    for (uint32_t i = threadIdx.x; i < G::WIN; i += 64u * NW) sh.ring_tag[i] = 0u;         // lap 0 expects 1
     if (threadIdx.x == 0) {
-        sh.dq_head = sh.dq_tail = sh.sq_head = sh.sq_tail = 0u;
+        sh.qctl = 0ull;
         sh.next_item = sh.committed = sh.commit_lock = sh.waves_done = 0u;
     }
     const uint32_t tile_x0 = blockIdx.x * G::PW, tile_y0 = blockIdx.y * G::PH;   // tile-local storage rows
@@ -188,10 +152,10 @@ __global__ void __launch_bounds__(64 * NW, 6) pathtrace_regroup_kernel(PTArgs a)
             c = __float_as_uint(acc.w);
             for (uint32_t k = 0; k < G::WIN / G::PB + 1u && c < n_samples; k++) {
                 const uint32_t item = c * G::PB + lane, slot = item % G::WIN;
-                if (rg_ld(reinterpret_cast<const uint32_t*>(&sh.ring[slot].w)) != item + 1u) break;
+                if (__hip_atomic_load(&sh.ring_tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (uint8_t)(item / G::WIN + 1u)) break;
                 rg_acquire();
-                const float4 e = sh.ring[slot];
-                acc.x += e.x; acc.y += e.y; acc.z += e.z;                                 // pathTracer.comp:452 (w += 0: dropped)
+                const v3 q = divs<Fast>(v3{sh.ring[0][slot], sh.ring[1][slot], sh.ring[2][slot]}, fspp);   // :452 accrad / samps.y
+                acc.x += q.x; acc.y += q.y; acc.z += q.z;                                 // (acc.w += 0: dropped)
                 c++;
             }
             acc.w = __uint_as_float(c);
@@ -211,6 +175,8 @@ __global__ void __launch_bounds__(64 * NW, 6) pathtrace_regroup_kernel(PTArgs a)
         }
     };
 
+    HotSlab hot;
+    hot.load<false>(sc);   // this kernel has no register headroom: scene constants stay scalar operands
     RgPath P;
     P.X = P.V = P.N = P.accmat = P.accrad = v3{0.0f, 0.0f, 0.0f};
     P.rx = P.ry = 0.0f; P.meta = 0u; P.pixkey = 0u;
@@ -219,154 +185,174 @@ __global__ void __launch_bounds__(64 * NW, 6) pathtrace_regroup_kernel(PTArgs a)
     // Hard bound far above the worst case (every item needs at most max_depth + 1 iterations of ONE lane): a logic error can
     // never leave a wave spinning on the device.
     const uint32_t guard_limit = total_items * (a.max_depth + 2u) + 1024u;
+    MC_TIME_INIT;
     for (uint32_t guard = 0; guard < guard_limit; guard++) {
         MC_REGION(9);    // scheduler iteration
+        MC_TIME_DECL;
         // ================================================================== swap point
-        {   // park the specular lanes
-            const bool is_spec = kind == RG_M || kind == RG_G;
-            const unsigned long long m = __ballot(is_spec);
-            if (m) {
-                const uint32_t base = rg_reserve_push(&sh.sq_tail, &sh.sq_head, (uint32_t)__popcll(m), G::SQ, lane);
-                if (base != 0xffffffffu) {
-                    const uint32_t ticket = base + rg_rank(m), slot = ticket % G::SQ;
-                    if (!rg_wait_seq(&sh.sq_seq[slot], ticket, is_spec)) { failed = true; break; }
-                    if (is_spec) {
-                        sh.sq_rec[0][slot] = make_float4(P.X.x, P.X.y, P.X.z, P.rx);
-                        sh.sq_rec[1][slot] = make_float4(P.V.x, P.V.y, P.V.z, __uint_as_float(kind));
-                        sh.sq_rec[2][slot] = make_float4(P.accmat.x, P.accmat.y, P.accmat.z, __uint_as_float(P.meta));
-                        sh.sq_rec[3][slot] = make_float4(P.accrad.x, P.accrad.y, P.accrad.z, __uint_as_float(P.pixkey));
-                        sh.sq_rec[4][slot] = make_float4(P.N.x, P.N.y, P.N.z, 0.0f);
-                        rg_release();
-                        rg_st(&sh.sq_seq[slot], ticket + 1u);
-                        kind = RG_EMPTY;
-                    }
-                }
-            }
-        }
-        unsigned long long m_empty = __ballot(kind == RG_EMPTY);
-        if (m_empty) {
-            const uint32_t v = (uint32_t)__popcll(m_empty);
-            // one snapshot of the control words (uniform addresses: broadcast reads)
-            const uint32_t dqh = rg_uniform(rg_ld(&sh.dq_head)), dqt = rg_uniform(rg_ld(&sh.dq_tail));
-            const uint32_t sqh = rg_uniform(rg_ld(&sh.sq_head)), sqt = rg_uniform(rg_ld(&sh.sq_tail));
+        // Latency matters as much as instruction count here: the LDS round trips of one swap point are (1) the control
+        // words, (2) the compare-and-swap TOGETHER WITH the sequence words of the slots it would grant, (3) the record
+        // writes and reads.  DS operations of a wave execute in issue order, so "data, then sequence word" needs no wait in
+        // between — only the compiler must keep the order (wavefront-scope fences).
+        const bool is_spec = (kind - RG_M) < 2u;
+        const unsigned long long m_spec = __ballot(is_spec);
+        const unsigned long long m_empty0 = __ballot(kind == RG_EMPTY);
+        if (m_spec | m_empty0) {
+            const bool is_d = kind == RG_D;
+            const unsigned long long m_d = __ballot(is_d);
+            const uint32_t n_s = (uint32_t)__popcll(m_spec), v0 = (uint32_t)__popcll(m_empty0), nd = (uint32_t)__popcll(m_d);
+            unsigned long long wv = __hip_atomic_load(&sh.qctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const uint32_t ni = rg_uniform(rg_ld(&sh.next_item)), cm = rg_uniform(rg_ld(&sh.committed));
-            const uint32_t d_avail = dqt - dqh, s_avail = sqt - sqh;
             const uint32_t limit = total_items < cm + G::WIN ? total_items : cm + G::WIN;
-            const uint32_t cam_avail = limit > ni ? limit - ni : 0u;
-            bool batch = false;
-            if (d_avail < v && s_avail + cam_avail >= kRgBatchMin) {
-                // BATCH: spill the D-ready lanes (the other waves' vacancies drain them), take specular + camera work
-                MC_REGION(11);   // batch
-                const bool is_d = kind == RG_D;
-                const unsigned long long m = __ballot(is_d);
-                batch = true;
-                if (m) {
-                    const uint32_t base = rg_reserve_push(&sh.dq_tail, &sh.dq_head, (uint32_t)__popcll(m), G::DQ, lane);
-                    if (base == 0xffffffffu) {
-                        batch = false;
-                    } else {
-                        const uint32_t ticket = base + rg_rank(m), slot = ticket % G::DQ;
-                        if (!rg_wait_seq(&sh.dq_seq[slot], ticket, is_d)) { failed = true; break; }
-                        if (is_d) {
-                            sh.dq_rec[0][slot] = make_float4(P.X.x, P.X.y, P.X.z, P.rx);
-                            sh.dq_rec[1][slot] = make_float4(P.V.x, P.V.y, P.V.z, P.ry);
-                            sh.dq_rec[2][slot] = make_float4(P.accmat.x, P.accmat.y, P.accmat.z, __uint_as_float(P.meta));
-                            sh.dq_rec[3][slot] = make_float4(P.accrad.x, P.accrad.y, P.accrad.z, __uint_as_float(P.pixkey));
-                            rg_release();
-                            rg_st(&sh.dq_seq[slot], ticket + 1u);
-                            kind = RG_EMPTY;
-                        }
+            const uint32_t cam_avail = rg_uniform(limit > ni ? limit - ni : 0u);
+            uint32_t push_s = 0, push_d = 0, pop_d = 0, pop_s = 0, s_avail_dbg = 0;
+            bool batch = false, more = false, reserved = false, bad = false;
+            bool push_on = false, pop_on = false;
+            uint32_t push_ticket = 0, push_slot = 0, pop_ticket = 0, pop_slot = 0, rank_e = 0;
+            unsigned long long m_e = m_empty0;
+            for (int tries = 0; tries < 16; tries++) {
+                // ---- all reservations of this swap point from one snapshot (scalar unit) ----
+                const uint32_t wlo = rg_uniform((uint32_t)wv), whi = rg_uniform((uint32_t)(wv >> 32));
+                const uint32_t dqh = wlo & 0xffffu, dqt = wlo >> 16, sqh = whi & 0xffffu, sqt = whi >> 16;
+                const uint32_t d_avail = (dqt - dqh) & 0xffffu, s_avail = (sqt - sqh) & 0xffffu;
+                s_avail_dbg = s_avail;
+                push_s = (s_avail + n_s <= Q) ? n_s : 0u;             // park the specular lanes (all or none)
+                const uint32_t v = v0 + push_s;                       // lanes to refill
+                push_d = 0u; pop_s = 0u; batch = false;
+                if (d_avail >= v) {
+                    pop_d = v; more = false;                          // the common case: D-ready paths for every vacancy
+                } else {
+                    more = true;
+                    batch = s_avail + cam_avail >= kRgBatchMin && d_avail + nd <= Q;
+                    if (batch) {   // spill the D-ready lanes (other waves' vacancies drain them), take specular + camera work
+                        push_d = nd; pop_d = 0u;
+                        pop_s = v + nd < s_avail ? v + nd : s_avail;
+                    } else {       // mixed iteration: whatever there is
+                        pop_d = d_avail;
+                        pop_s = v - pop_d < s_avail ? v - pop_d : s_avail;
                     }
+                }
+                m_e = m_empty0 | (push_s ? m_spec : 0ull) | (push_d ? m_d : 0ull);   // lanes empty once the pushes are out
+                rank_e = rg_rank(m_e);
+                if ((push_s | push_d | pop_d | pop_s) == 0u) { reserved = true; break; }
+                // ---- per-lane roles under this (tentative) reservation ----
+                push_on = (is_spec && push_s != 0u) || (is_d && push_d != 0u);
+                push_ticket = sqt + rg_rank(m_spec);
+                if (push_d) push_ticket = is_spec ? push_ticket : dqt + rg_rank(m_d);
+                push_slot = (push_ticket & (Q - 1u)) | (is_spec ? Q : 0u);
+                const bool from_d = rank_e < pop_d;
+                pop_on = ((m_e >> lane) & 1ull) != 0ull && rank_e < pop_d + pop_s;
+                pop_ticket = from_d ? dqh + rank_e : sqh + (rank_e - pop_d);
+                pop_slot = (pop_ticket & (Q - 1u)) | (from_d ? 0u : Q);
+                // ---- one round trip: the compare-and-swap and the sequence words of the slots it would grant ----
+                const uint32_t nlo = ((dqh + pop_d) & 0xffffu) | ((dqt + push_d) << 16);
+                const uint32_t nhi = ((sqh + pop_s) & 0xffffu) | ((sqt + push_s) << 16);
+                unsigned long long ov = wv;
+                if (lane == 0) ov = atomicCAS(&sh.qctl, wv, (unsigned long long)nlo | ((unsigned long long)nhi << 32));
+                uint32_t sq_push = push_on ? rg_ld(&sh.seq[push_slot]) : 0u;
+                uint32_t sq_pop = pop_on ? rg_ld(&sh.seq[pop_slot]) : 0u;
+                const uint32_t olo = rg_uniform((uint32_t)ov), ohi = rg_uniform((uint32_t)(ov >> 32));
+                if (olo != wlo || ohi != whi) {                       // another wave got in between: decide again
+                    wv = (unsigned long long)olo | ((unsigned long long)ohi << 32);
+                    continue;
+                }
+                reserved = true;
+                // the slot's previous reader (push) / the record's writer (pop) may still be at work: rarely, briefly
+                for (uint32_t spins = 0;; spins++) {
+                    const bool ok = (!push_on || sq_push == (push_ticket & 0xffffu)) && (!pop_on || sq_pop == ((pop_ticket + 1u) & 0xffffu));
+                    if (__ballot(!ok) == 0ull) break;
+                    if (spins >= kRgSpinLimit) { bad = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    if (push_on) sq_push = rg_ld(&sh.seq[push_slot]);
+                    if (pop_on) sq_pop = rg_ld(&sh.seq[pop_slot]);
+                }
+                break;
+            }
+            MC_TIME_MARK(4);   // swap: control words + reservation
+            if (bad) { failed = true; break; }
+            if (!reserved) { push_s = push_d = pop_d = pop_s = 0u; batch = false; more = false; push_on = pop_on = false; m_e = m_empty0; rank_e = rg_rank(m_e); }
+            if (batch) { MC_REGION(11); }
+            if (!reserved) { MC_REGION(13); }
+            if (more && !batch) { MC_REGION(14); }
+            if (n_s && !push_s) { MC_REGION(15); }
+            MC_ACCUM(7, cam_avail);
+            MC_ACCUM(8, s_avail_dbg);
+            MC_ACCUM(2, ni - cm);
+            (void)s_avail_dbg;
+
+            // ---- pushes: specular lanes -> SQ, (batch) D-ready lanes -> DQ; one write sequence, then the sequence word ----
+            if (push_s | push_d) {
+                if (push_on) {
+                    const uint32_t slot = push_slot;
+                    sh.rec[0][slot] = P.X.x; sh.rec[1][slot] = P.X.y; sh.rec[2][slot] = P.X.z;
+                    sh.rec[3][slot] = P.V.x; sh.rec[4][slot] = P.V.y; sh.rec[5][slot] = P.V.z;
+                    sh.rec[6][slot] = P.N.x; sh.rec[7][slot] = P.N.y; sh.rec[8][slot] = P.N.z;
+                    sh.rec[9][slot] = P.accmat.x; sh.rec[10][slot] = P.accmat.y; sh.rec[11][slot] = P.accmat.z;
+                    sh.rec[12][slot] = P.accrad.x; sh.rec[13][slot] = P.accrad.y; sh.rec[14][slot] = P.accrad.z;
+                    sh.rec[15][slot] = P.rx; sh.rec[16][slot] = P.ry;
+                    sh.rec[17][slot] = __uint_as_float(P.meta | (kind << 30));   // item, depth | kind (1..3)
+                    sh.rec[18][slot] = __uint_as_float(P.pixkey);
+                    rg_order();
+                    rg_st(&sh.seq[slot], (push_ticket + 1u) & 0xffffu);
+                    kind = RG_EMPTY;
                 }
             }
-            bool more = batch || d_avail < v;   // also take specular / camera work (mixed iteration unless it is a batch)
-            if (!batch && d_avail) {
-                // refill the vacated lanes with D-ready paths
-                const bool want = kind == RG_EMPTY;
-                const unsigned long long m = __ballot(want);
-                uint32_t granted;
-                const uint32_t base = rg_reserve_pop(&sh.dq_head, &sh.dq_tail, (uint32_t)__popcll(m), lane, granted);
-                const uint32_t rank = rg_rank(m);
-                const bool mine = want && rank < granted;
-                const uint32_t ticket = base + rank, slot = ticket % G::DQ;
-                if (granted) {
-                    if (!rg_wait_seq(&sh.dq_seq[slot], ticket + 1u, mine)) { failed = true; break; }
-                    rg_acquire();
-                    if (mine) {
-                        const float4 r0 = sh.dq_rec[0][slot], r1 = sh.dq_rec[1][slot], r2 = sh.dq_rec[2][slot], r3 = sh.dq_rec[3][slot];
-                        P.X = v3{r0.x, r0.y, r0.z}; P.rx = r0.w;
-                        P.V = v3{r1.x, r1.y, r1.z}; P.ry = r1.w;
-                        P.accmat = v3{r2.x, r2.y, r2.z}; P.meta = __float_as_uint(r2.w);
-                        P.accrad = v3{r3.x, r3.y, r3.z}; P.pixkey = __float_as_uint(r3.w);
-                        kind = RG_D;
-                        rg_release();                                   // the reads above are complete before the slot is freed
-                        rg_st(&sh.dq_seq[slot], ticket + G::DQ);
-                    }
+            // ---- pops: D-ready paths, then parked specular ones, into the empty lanes; one read sequence ----
+            const bool is_empty = ((m_e >> lane) & 1ull) != 0ull;
+            if (pop_d | pop_s) {
+                rg_order();
+                if (pop_on) {
+                    const uint32_t slot = pop_slot;
+                    P.X = v3{sh.rec[0][slot], sh.rec[1][slot], sh.rec[2][slot]};
+                    P.V = v3{sh.rec[3][slot], sh.rec[4][slot], sh.rec[5][slot]};
+                    P.N = v3{sh.rec[6][slot], sh.rec[7][slot], sh.rec[8][slot]};
+                    P.accmat = v3{sh.rec[9][slot], sh.rec[10][slot], sh.rec[11][slot]};
+                    P.accrad = v3{sh.rec[12][slot], sh.rec[13][slot], sh.rec[14][slot]};
+                    P.rx = sh.rec[15][slot]; P.ry = sh.rec[16][slot];
+                    const uint32_t km = __float_as_uint(sh.rec[17][slot]);
+                    P.pixkey = __float_as_uint(sh.rec[18][slot]);
+                    kind = km >> 30; P.meta = km & 0x3fffffffu;
+                    rg_order();                                     // issued after the reads: the slot is freed behind them
+                    rg_st(&sh.seq[slot], (pop_ticket + Q) & 0xffffu);
                 }
             }
-            if (more) {
-                {   // parked specular paths
-                    const bool want = kind == RG_EMPTY;
-                    const unsigned long long m = __ballot(want);
-                    if (m && s_avail) {
-                        uint32_t granted;
-                        const uint32_t base = rg_reserve_pop(&sh.sq_head, &sh.sq_tail, (uint32_t)__popcll(m), lane, granted);
-                        const uint32_t rank = rg_rank(m);
-                        const bool mine = want && rank < granted;
-                        const uint32_t ticket = base + rank, slot = ticket % G::SQ;
-                        if (granted) {
-                            if (!rg_wait_seq(&sh.sq_seq[slot], ticket + 1u, mine)) { failed = true; break; }
-                            rg_acquire();
-                            if (mine) {
-                                const float4 r0 = sh.sq_rec[0][slot], r1 = sh.sq_rec[1][slot], r2 = sh.sq_rec[2][slot],
-                                             r3 = sh.sq_rec[3][slot], r4 = sh.sq_rec[4][slot];
-                                P.X = v3{r0.x, r0.y, r0.z}; P.rx = r0.w;
-                                P.V = v3{r1.x, r1.y, r1.z}; kind = __float_as_uint(r1.w);
-                                P.accmat = v3{r2.x, r2.y, r2.z}; P.meta = __float_as_uint(r2.w);
-                                P.accrad = v3{r3.x, r3.y, r3.z}; P.pixkey = __float_as_uint(r3.w);
-                                P.N = v3{r4.x, r4.y, r4.z};
-                                rg_release();
-                                rg_st(&sh.sq_seq[slot], ticket + G::SQ);
-                            }
-                        }
-                    }
+            MC_TIME_MARK(5);   // swap: record writes + reads
+            // ---- fresh camera samples for the lanes still empty, inside the reorder window ----
+            const uint32_t want_cam = more ? (uint32_t)__popcll(m_e) - (pop_d + pop_s) : 0u;
+            if (want_cam && cam_avail) {
+                uint32_t base = 0, got = 0, iv = ni;
+                for (int k = 0; k < 16; k++) {
+                    const uint32_t i = rg_uniform(iv);
+                    const uint32_t c2 = rg_uniform(rg_ld(&sh.committed));
+                    const uint32_t lim = total_items < c2 + G::WIN ? total_items : c2 + G::WIN;
+                    const uint32_t avail = lim > i ? lim - i : 0u;
+                    const uint32_t g = avail < want_cam ? avail : want_cam;
+                    if (g == 0u) break;
+                    uint32_t o = i;
+                    if (lane == 0) o = atomicCAS(&sh.next_item, i, i + g);
+                    o = rg_uniform(o);
+                    if (o == i) { base = i; got = g; break; }
+                    iv = o;
                 }
-                {   // fresh camera samples, inside the reorder window
-                    const bool want = kind == RG_EMPTY;
-                    const unsigned long long m = __ballot(want);
-                    if (m && cam_avail) {
-                        const uint32_t n = (uint32_t)__popcll(m);
-                        uint32_t base = 0, got = 0;
-                        if (lane == 0) {
-                            uint32_t i = rg_ld(&sh.next_item);
-                            for (int k = 0; k < 64; k++) {
-                                const uint32_t c2 = rg_ld(&sh.committed);
-                                const uint32_t lim = total_items < c2 + G::WIN ? total_items : c2 + G::WIN;
-                                const uint32_t avail = lim > i ? lim - i : 0u;
-                                const uint32_t g = avail < n ? avail : n;
-                                if (g == 0u) break;
-                                const uint32_t o = atomicCAS(&sh.next_item, i, i + g);
-                                if (o == i) { base = i; got = g; break; }
-                                i = o;
-                            }
-                        }
-                        base = rg_uniform(base); got = rg_uniform(got);
-                        const uint32_t rank = rg_rank(m);
-                        if (want && rank < got) { kind = RG_CAM; P.meta = base + rank; }
-                    }
-                }
+                const uint32_t r = rank_e - (pop_d + pop_s);          // (wraps for the lanes that popped: r >= got)
+                if (is_empty && rank_e >= pop_d + pop_s && r < got) { kind = RG_CAM; P.meta = base + r; }
             }
-            if (batch || cam_avail < v) try_commit();   // a batch is a natural cadence; otherwise only under window pressure
+            MC_TIME_MARK(6);   // swap: camera items
+            // a batch is the natural cadence; otherwise fold as soon as the window (not the work) limits the camera samples
+            if (batch || cam_avail < 64u + v0 + n_s) try_commit();
+            MC_TIME_MARK(7);   // swap: commit
         }
 
+        MC_TIME_MARK(0);   // swap point
         // ================================================================== nothing to run in this wave?
         if (__ballot(kind != RG_EMPTY) == 0ull) {
-            const uint32_t dqh = rg_uniform(rg_ld(&sh.dq_head)), dqt = rg_uniform(rg_ld(&sh.dq_tail));
-            const uint32_t sqh = rg_uniform(rg_ld(&sh.sq_head)), sqt = rg_uniform(rg_ld(&sh.sq_tail));
+            const unsigned long long w = rg_uniform64(__hip_atomic_load(&sh.qctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             const uint32_t ni = rg_uniform(rg_ld(&sh.next_item));
             // everything handed out and nothing parked: whatever is still in flight sits in the lanes of other waves,
             // which finish it themselves (a wave pops what it pushed if nobody else does)
-            if (ni >= total_items && dqt == dqh && sqt == sqh) break;
+            if (ni >= total_items && (uint32_t)(w & 0xffffu) == (uint32_t)((w >> 16) & 0xffffu) &&
+                (uint32_t)((w >> 32) & 0xffffu) == (uint32_t)(w >> 48))
+                break;
             MC_REGION(12);   // idle spin
             try_commit();                        // the window may be what holds the camera samples back
             __builtin_amdgcn_s_sleep(8);
@@ -377,9 +363,11 @@ __global__ void __launch_bounds__(64 * NW, 6) pathtrace_regroup_kernel(PTArgs a)
 
         // ================================================================== heads: bring every lane to "ray ready"
         // After this block X = ray origin, V = ray direction, and `depth` is the depth of the intersect that follows.
-        uint32_t depth = rg_depth(P.meta);
-        float emissive = 1.0f;                                                // pathTracer.comp:365,434,447
-        bool fin = false;
+        // (depth / emissive / fin are functions of the kind: computed outside the branches so that the heads only touch the
+        //  path fields they change — fewer values to merge behind the branches)
+        const uint32_t depth = rg_depth(P.meta) + (kind != RG_CAM ? 1u : 0u);   // depth of the intersect that follows
+        const float emissive = kind == RG_D ? 0.0f : 1.0f;                    // pathTracer.comp:365,429,434,447
+        bool fin = depth >= a.max_depth;                                      // (camera: depth 0)
         if (kind == RG_CAM) {
             MC_REGION(0);   // ray generation
             const uint32_t item = P.meta;                                      // meta = item, depth 0
@@ -402,9 +390,9 @@ __global__ void __launch_bounds__(64 * NW, 6) pathtrace_regroup_kernel(PTArgs a)
                 v3 spos = (a.cam_o + a.cx * sx) + a.cy * sy;                   // :360
                 P.X = a.lc;
                 P.V = normalize<Fast>(a.lc - spos);                            // :362
-                fin = a.max_depth == 0u;
             }
-        } else if (kind == RG_D) {
+        }
+        if (kind == RG_D) {
             MC_REGION(3);   // diffuse: NEE set-up + shadow ray + bounce direction
             const v3 x = P.X, nl = P.V;
             for (int i = 0; i < NS; i++) {                                    // :403
@@ -424,7 +412,7 @@ __global__ void __launch_bounds__(64 * NW, 6) pathtrace_regroup_kernel(PTArgs a)
                 dm::sincos_angle<Fast>(phi, P.ry, sphi, cphi);
                 v3 l = normalize<Fast>(((su * cphi) * sin_a + (sv * sphi) * sin_a) + sw * cos_a);   // :413
                 float tne;
-                int idne = intersect<Fast, NP, NS, true, 0>(sc, uobj, x, l, tne, sc.nee_skip_planes != 0u);   // :420 shadow ray
+                int idne = intersect_slab<Fast>(hot, x, l, tne, sc.nee_skip_planes != 0u);   // :420 shadow ray
                 if (idne == NP + i) {
                     float omega = (2.0f * kPi) * (1.0f - cos_a_max);          // :421
                     P.accrad = P.accrad + ((divs<Fast>(P.accmat, kPi) * dm::gmax(dot(l, nl), 0.0f)) * le) * omega;   // :422
@@ -437,15 +425,12 @@ __global__ void __launch_bounds__(64 * NW, 6) pathtrace_regroup_kernel(PTArgs a)
             float s1, c1;
             dm::sincos_angle<Fast>(r1, P.rx, s1, c1);
             P.V = normalize<Fast>(((u * c1) * r2s + (vv * s1) * r2s) + w * dm::fsqrt<Fast>(1.0f - r2));   // :428
-            emissive = 0.0f;                                                  // :429
-            depth++;
-            fin = depth >= a.max_depth;
-        } else if (kind == RG_M) {                                            // :432 mirror
+        }
+        if (kind == RG_M) {                                                   // :432 mirror
             MC_REGION(5);
             P.V = reflect(P.V, P.N);
-            depth++;
-            fin = depth >= a.max_depth;
-        } else if (kind == RG_G) {                                            // :437 glass
+        }
+        if (kind == RG_G) {                                                   // :437 glass
             MC_PT_DECISION_FP
             MC_REGION(6);
             const v3 rd0 = P.V, n = P.N;
@@ -472,10 +457,9 @@ __global__ void __launch_bounds__(64 * NW, 6) pathtrace_regroup_kernel(PTArgs a)
             } else {
                 P.V = refl;                                                   // :446
             }
-            depth++;
-            fin = depth >= a.max_depth;
         }
 
+        MC_TIME_MARK(1);   // heads
         // ================================================================== intersect + bounce prologue
         if (kind != RG_EMPTY && !fin) {
             MC_REGION(1);
@@ -483,11 +467,10 @@ __global__ void __launch_bounds__(64 * NW, 6) pathtrace_regroup_kernel(PTArgs a)
             const uint32_t samp = a.sample_begin + rg_item(P.meta) / G::PB;
             const v3 ro = P.X, rd = P.V;
             float t;
-            const int id = intersect<Fast, NP, NS, true, 0>(sc, uobj, ro, rd, t);
+            const int id = intersect_slab<Fast>(hot, ro, rd, t, false);
             if (id < 0) {
                 fin = true;   // :369 `continue` with an unchanged ray misses again at every later depth: the path is over
             } else {
-                MC_REGION(2);
                 v3 x = ro + rd * t;                                           // :374
                 const float* obj = lds_obj + 12 * id;                         // per-lane fetch from LDS
                 const bool is_sphere = id >= NP;
@@ -514,18 +497,20 @@ __global__ void __launch_bounds__(64 * NW, 6) pathtrace_regroup_kernel(PTArgs a)
             }
         }
 
+        MC_TIME_MARK(2);   // intersect + prologue
         // ================================================================== finished samples -> reorder ring
         if (kind != RG_EMPTY && fin) {
             MC_REGION(10);
             const uint32_t item = rg_item(P.meta), slot = item % G::WIN;
-            const v3 q = divs<Fast>(P.accrad, fspp);                          // :452 accrad / samps.y
-            sh.ring[slot] = make_float4(q.x, q.y, q.z, 0.0f);
-            rg_release();
-            rg_st(reinterpret_cast<uint32_t*>(&sh.ring[slot].w), item + 1u);
+            sh.ring[0][slot] = P.accrad.x; sh.ring[1][slot] = P.accrad.y; sh.ring[2][slot] = P.accrad.z;   // divided by spp at the fold
+            rg_order();
+            __hip_atomic_store(&sh.ring_tag[slot], (uint8_t)(item / G::WIN + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             kind = RG_EMPTY;
         }
+        MC_TIME_MARK(3);   // retire
     }
 
+    MC_TIME_FLUSH;
     // ---- the last wave to leave folds what remains and writes the tile ----
     if (failed && lane == 0 && a.status) atomicOr(a.status, 1u);
     rg_release();
