@@ -1,29 +1,31 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the hot path on MI355X (driver contract).
 
-  python bench.py --gpus N --steps K --warmup W [--workload pathtrace|mandelbrot|mandelbrot_ds]
+  python bench.py --gpus N --steps K --warmup W [--config K2|K1|K1ds|K3|K4]
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path over one synthetic batch:
-  pathtrace (default, BASELINE config K2): render the 900 x 600 default scene at 500 spp — one fused
-      HIP launch per rank — and, for N > 1, gather the fp32 row tiles to rank 0 over RCCL and
-      re-assemble the storage buffer there.
-  mandelbrot (BASELINE config K1): 3200 x 2400, M = 1000, fp32.  mandelbrot_ds: the two-float variant.
-Weak scaling: per-GPU work is fixed, the image grows to W x (H*N) rows, interleaved row blocks (mc_row_block() = 8 rows) per
-rank (every pixel is keyed by its absolute coordinates, so tiling never changes a pixel's arithmetic;
-samples are never split across GPUs — the fp32 accumulation order is part of the parity contract).
+A "step" is one pass of the hot path over one synthetic batch (BASELINE.json configs):
+  K2 (default, the headline): path trace 900 x 600, 500 spp, default scene.      WEAK scaling: image W x (600 N).
+  K1: Mandelbrot 3200 x 2400, M = 1000, fp32;  K1ds: its two-float variant.       WEAK scaling: image W x (2400 N).
+  K3: path trace 3840 x 2560, 4096 spp — BASELINE's 8-GPU path-trace config.      STRONG scaling: the whole image on N ranks.
+  K4: Mandelbrot deep zoom 7680 x 5120, M = 50 000, two-float — the 8-GPU one.    STRONG scaling.
+For N > 1 every rank renders its interleaved row blocks (mc_row_block() = 8 rows; every pixel is keyed by its absolute
+coordinates, so tiling never changes a pixel's arithmetic; samples are never split across GPUs — the fp32 accumulation
+order is part of the parity contract), then the fp32 tiles are gathered to rank 0 over RCCL and re-assembled there.
+`--verify` re-renders the whole image on rank 0 after the timed region and requires bit-identity with the gathered one.
 
-Output buffers are resident in HBM (torch tensors); there are no inputs besides 432 B of scene
-constants.  The timed region is bracketed by barrier + torch.cuda.synchronize() on both sides; the
-value is whole-job units / max-over-ranks time.  One JSON line is printed by rank 0.
+Output buffers are resident in HBM (torch tensors); there are no inputs besides 432 B of scene constants.  The timed
+region is bracketed by barrier + torch.cuda.synchronize() on both sides; value = whole-job units / max-over-ranks time.
+One JSON line is printed by rank 0.
 
 `roofline`: fp32 VALU (neither HBM nor MFMA bounds this path: 16 B written per pixel, no contraction).
-   achieved = algorithmic fp32 flops per launch (flops/unit from the oracle's op counters) /
-   mean kernel time measured with HIP events on the launch stream; peak = 157.3 TFLOP/s (FMA-counted,
-   MI355X_MICROARCH.md).  `lane_ops` adds the issue-slot view (78.6e12 lane-ops/s at 2.4 GHz): with
-   no contraction allowed every flop occupies a slot, so 0.5 of the FMA-counted peak is the ceiling.
-`cpu_baseline`: the CPU oracle (a port, not the reference's Vulkan build — lavapipe/glslang are absent)
-   timed on this host's cores over a bounded sample of the same workload.
+   achieved = algorithmic fp32 flops per step (flops/unit from the oracle's op counters) / mean kernel time of a
+   step, measured with HIP events on the launch stream; peak = 157.3 TFLOP/s (FMA-counted, MI355X_MICROARCH.md).
+   `lane_ops` adds the issue-slot view (78.6e12 lane-ops/s at 2.4 GHz): parity forbids contraction, so every flop occupies
+   a slot and 0.5 of the FMA-counted peak is the ceiling.  `traffic` = HBM bytes per step from the rocprofv3 PMC pass
+   committed under profiles/ (summed over ALL launches of a step), with `traffic_source` naming the file.
+`cpu_baseline`: the CPU oracle (a port, not the reference's Vulkan build — lavapipe/glslang are absent on the GPU box, which
+   receives only this repository) timed on this host's cores over a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -41,50 +43,79 @@ FLOPS_PER_SAMPLE_PT = 3809.0        # oracle counters, 900x600 default scene: ad
 PEAK_FP32_TFLOPS = 157.3            # MI355X vector fp32, FMA counted as 2 (v_pk_fma_f32 only)
 PEAK_LANE_OPS = 78.6e12             # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (v_add/v_mul issue rate)
 
-K2 = dict(W=900, H=600, spp=500)
-K1 = dict(W=3200, H=2400, M=1000)
 K4_VIEW = dict(centre=(-0.7436438870371587, 0.13182590420531198), scale=(1e-8, 1e-8 * 2.0 / 3.0))
+CONFIGS = {
+    #        kind          W     H     spp / M      two-float  scaling
+    "K2":   dict(kind="pt", W=900, H=600, spp=500, scaling="weak"),
+    "K1":   dict(kind="mandel", W=3200, H=2400, M=1000, ds=False, scaling="weak"),
+    "K1ds": dict(kind="mandel", W=3200, H=2400, M=1000, ds=True, scaling="weak"),
+    "K3":   dict(kind="pt", W=3840, H=2560, spp=4096, scaling="strong"),
+    "K4":   dict(kind="mandel", W=7680, H=5120, M=50000, ds=True, scaling="strong"),
+}
+WORKLOAD_ALIAS = {"pathtrace": "K2", "mandelbrot": "K1", "mandelbrot_ds": "K1ds"}
+PROFILE_TAG = {"K2": {"fast": "pt_fast", "strict": "pt_strict"}, "K1": "mandel", "K1ds": "mandel_ds"}
 
 
-def profiled_traffic(wl, args, n):
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC pass committed under profiles/
-    (WRITE_SIZE in its own --pmc pass; exact for 16-B-per-lane stores, MI355X_MICROARCH.md §HBM; these kernels
-    read nothing but a <1 MB LUT / 432 B of scene).  None when the run is not the profiled default configuration."""
-    if n != 1 or args.width or args.height or args.spp:
-        return None
-    tag = {"pathtrace": "pt_fast" if args.math == "fast" else "pt_strict", "mandelbrot": "mandel",
-           "mandelbrot_ds": "mandel_ds"}[wl]
-    for rnd in ("r01d", "r01c", "r01b"):
+def profiled_traffic(cfg_name, args, n):
+    """HBM bytes per STEP from the rocprofv3 PMC pass committed under profiles/ (WRITE_SIZE in its own --pmc pass, exact for
+    16-B-per-lane stores, MI355X_MICROARCH.md §HBM), summed over every launch of a step (a K2 step is two launches: the
+    S = 16 rounds and the 4-sample tail, which also re-reads the 8.64 MB accumulator it continues — added as algorithmic
+    bytes, FETCH_SIZE being uncalibrated for lane-sparse loads).  (None, None) when the run is not a profiled configuration."""
+    if n != 1 or args.width or args.height or args.spp or cfg_name not in PROFILE_TAG:
+        return None, None
+    tag = PROFILE_TAG[cfg_name]
+    if isinstance(tag, dict):
+        tag = tag[args.math]
+    for rnd in ("r02", "r01d", "r01c"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}_pmc_summary.json")
         if os.path.exists(path):
             try:
-                for entry in json.load(open(path)).values():
+                entries = json.load(open(path))
+                total, launches = 0.0, 0
+                for name, entry in entries.items():
                     b = entry.get("derived", {}).get("hbm_write_bytes")
-                    if b:
-                        return b
+                    if b and ("pathtrace_kernel" in name or "mandelbrot_kernel" in name):
+                        total += b
+                        launches += 1
+                if not launches:
+                    return None, None
+                note = f"profiles/{os.path.basename(path)}: WRITE_SIZE summed over the {launches} launch(es) of a step"
+                if cfg_name == "K2" and launches == 2:
+                    total += 900 * 600 * 16
+                    note += " + the tail launch's 8.64 MB accumulator read (algorithmic)"
+                return total, note
             except (ValueError, OSError):
-                return None
-    return None
+                return None, None
+    return None, None
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="pathtrace", choices=["pathtrace", "mandelbrot", "mandelbrot_ds"])
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 10; 3 for K3, whose step is 4e10 samples)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 2; 1 for K3)")
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="BASELINE configuration (default K2)")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOAD_ALIAS), help="round-1 spelling of --config")
     ap.add_argument("--math", default="fast", choices=["fast", "strict"],
-                    help="path tracer math mode: fast = gfx950 hardware transcendentals (toleranced parity), "
-                         "strict = IEEE + mc math (bit-identical to the oracle)")
+                    help="path tracer math mode: fast = gfx950 hardware transcendentals + contraction (toleranced parity, "
+                         "tests/test_gpu_fullsize.py pins it at K2), strict = IEEE + mc math (bit-identical to the oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--spp", type=int, default=None, help="override spp (diagnostics only; invalidates the headline)")
     ap.add_argument("--width", type=int, default=None, help="override image width (diagnostics only)")
-    ap.add_argument("--height", type=int, default=None, help="override per-GPU image height (diagnostics only)")
+    ap.add_argument("--height", type=int, default=None, help="override image height (per GPU for weak scaling; diagnostics only)")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed region, rank 0 re-renders the whole image on its own GPU and checks that the "
                          "gathered N-rank image is bit-identical (multi-GPU == single-GPU invariant, SURVEY §8e)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.config and a.workload and WORKLOAD_ALIAS[a.workload] != a.config:
+        ap.error("--config and --workload disagree")
+    a.config = a.config or (WORKLOAD_ALIAS[a.workload] if a.workload else "K2")
+    if a.steps is None:
+        a.steps = 3 if a.config == "K3" else 10
+    if a.warmup is None:
+        a.warmup = 1 if a.config == "K3" else 2
+    return a
 
 
 def main():
@@ -130,21 +161,23 @@ def main():
     assert stream != 0
 
     # ---- workload ---------------------------------------------------------------------------------
-    wl = args.workload
-    if wl == "pathtrace":
-        W, Hbase, spp = args.width or K2["W"], args.height or K2["H"], args.spp or K2["spp"]
-        H = Hbase * n
+    cfg_name = args.config
+    cfg = CONFIGS[cfg_name]
+    is_pt = cfg["kind"] == "pt"
+    weak = cfg["scaling"] == "weak"
+    W = args.width or cfg["W"]
+    H = (args.height or cfg["H"]) * (n if weak else 1)
+    if is_pt:
+        spp = args.spp or cfg["spp"]
         math_mode = B.PT_MATH_FAST if args.math == "fast" else B.PT_MATH_STRICT
         pt_flags = int(os.environ.get("MC_PT_FLAGS", "0"), 0)    # experiments only (mc_pathtrace_params.flags)
         p = S.shard(B.pathtrace_params(W, H, spp, math_mode=math_mode, flags=pt_flags), rank, n)
         units_per_step = W * H * spp                         # samples
         flops_per_unit = FLOPS_PER_SAMPLE_PT
         metric, unit = "path-traced samples/s", "samples/s"
-        workload_name = f"pathtrace {W}x{H} spp{spp} default-scene math={args.math}"
+        workload_name = f"{cfg_name}: pathtrace {W}x{H} spp{spp} default-scene math={args.math}"
     else:
-        W, Hbase, M = args.width or K1["W"], args.height or K1["H"], K1["M"]
-        H = Hbase * n
-        ds = wl == "mandelbrot_ds"
+        M, ds = cfg["M"], cfg["ds"]
         kw = dict(max_iter=M)
         if ds:
             kw.update(precision=B.PRECISION_DS, centre=K4_VIEW["centre"], scale=K4_VIEW["scale"])
@@ -152,30 +185,35 @@ def main():
         units_per_step = None                                # pixel-iters: data dependent, counted after the run
         flops_per_unit = FLOPS_PER_PIXEL_ITER_DS if ds else FLOPS_PER_PIXEL_ITER_F32
         metric, unit = "Mandelbrot pixel-iters/s", "pixel-iters/s"
-        workload_name = f"mandelbrot{'_ds' if ds else ''} {W}x{H} M{M}"
+        workload_name = f"{cfg_name}: mandelbrot{'_ds' if ds else ''} {W}x{H} M{M}"
 
+    owns = S.owns_rows(p)                                     # False for a rank beyond the last row block (renders nothing)
     rows_local = B.tile_rows(p)
     rows_padded = S.padded_tile_rows(H, n) if n > 1 else rows_local
     tile = torch.zeros((rows_padded, W, 4), dtype=torch.float32, device="cuda")
-    iters_t = torch.zeros((rows_padded, W), dtype=torch.int32, device="cuda") if wl != "pathtrace" else None
+    iters_t = torch.zeros((rows_padded, W), dtype=torch.int32, device="cuda") if not is_pt else None
     full = torch.empty((H, W, 4), dtype=torch.float32, device="cuda") if n > 1 and rank == 0 else None
 
     ev_k0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev_k1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev_g1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
     def step(i=None):
         if i is not None:
             ev_k0[i].record()
-        if wl == "pathtrace":
-            ctx.pathtrace_device(p, tile.data_ptr(), stream=stream)
-        else:
-            ctx.mandelbrot_device(p, tile.data_ptr(), iters_t.data_ptr(), stream=stream)
+        if owns:
+            if is_pt:
+                ctx.pathtrace_device(p, tile.data_ptr(), stream=stream)
+            else:
+                ctx.mandelbrot_device(p, tile.data_ptr(), iters_t.data_ptr(), stream=stream)
         if i is not None:
             ev_k1[i].record()
         if n > 1:
             gathered = S.gather_tiles(tile, rank, n)          # RCCL gather of the fp32 tiles to rank 0
             if rank == 0:
                 S.assemble_device(ctx, gathered, W, H, n, full, stream=stream)
+            if i is not None:
+                ev_g1[i].record()
 
     def fence():
         if n > 1:
@@ -195,9 +233,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_k0, ev_k1)]))
+    gather_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_k1, ev_g1)])) if n > 1 else 0.0
 
     # ---- units ------------------------------------------------------------------------------------
-    if wl == "pathtrace":
+    if is_pt:
         local_units = W * rows_local * p.spp
     else:
         it = iters_t[:rows_local].to(torch.int64)
@@ -211,6 +250,18 @@ def main():
             units_per_step = local_units
     value = units_per_step * args.steps / dt
 
+    # ---- per-rank evidence: who rendered what on which device, how long (gathered to rank 0) ----------------------
+    ranks_info = None
+    if n > 1:
+        mine = torch.tensor([rank, device_index, rows_local, local_units, kernel_ms, gather_ms, dist.get_world_size()],
+                            dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        allv = [torch.empty_like(mine) for _ in range(n)] if rank == 0 else None
+        dist.gather(mine, allv, dst=0)
+        if rank == 0:
+            ranks_info = [{"rank": int(v[0]), "device": int(v[1]), "rows": int(v[2]), "units_per_step": int(v[3]),
+                           "kernel_ms": round(float(v[4]), 4), "gather_ms": round(float(v[5]), 4),
+                           "world_size_seen": int(v[6])} for v in (t.cpu() for t in allv)]
+
     # ---- optional self-check: N-rank image == single-GPU image, bit for bit (outside the timed region) ----------
     verified = None
     if args.verify and n > 1 and rank == 0:
@@ -218,7 +269,7 @@ def main():
         q = copy.copy(p)
         q.row_begin, q.row_end, q.row_block, q.row_stride = 0, H, 0, 0
         single = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-        if wl == "pathtrace":
+        if is_pt:
             ctx.pathtrace_device(q, single.data_ptr(), stream=stream)
         else:
             ctx.mandelbrot_device(q, single.data_ptr(), 0, stream=stream)
@@ -230,42 +281,50 @@ def main():
     out = None
     if rank == 0:
         achieved_tflops = local_units * flops_per_unit / (kernel_ms * 1e-3) / 1e12
-        kern = {"pathtrace": "pathtrace_kernel", "mandelbrot": "mandelbrot_kernel<StateF32>",
-                "mandelbrot_ds": "mandelbrot_kernel<StateDS>"}[wl]
+        kern = "pathtrace_kernel" if is_pt else ("mandelbrot_kernel<StateDS>" if cfg["ds"] else "mandelbrot_kernel<StateF32>")
+        traffic, traffic_source = profiled_traffic(cfg_name, args, n)
+        bytes_per_pixel = 16 if is_pt else 20
+        if is_pt and n == 1 and (p.spp % 16) and p.spp > 16:
+            alg_bytes = W * rows_local * 16 * 3      # two launches: rounds (write), ragged tail (read + write)
+        else:
+            alg_bytes = W * rows_local * bytes_per_pixel
         out = {
             "metric": metric, "value": value, "unit": unit, "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload_name, "image": [W, H], "rows_per_gpu": rows_local,
+            "config": {"workload": workload_name, "baseline_config": cfg_name, "image": [W, H], "rows_per_gpu": rows_local,
                        "tiling": "whole image" if n == 1 else f"interleaved {ROW_BLOCK}-row blocks, RCCL gather to rank 0",
                        "device": dev_name, "compute_units": cus,
+                       **({"backend": backend, "world_size": dist.get_world_size(), "ranks": ranks_info,
+                           "gather_ms_rank0": round(gather_ms, 4),
+                           "gather_note": "kernel end -> gathered + re-assembled on rank 0; includes waiting for the slowest rank"}
+                          if n > 1 else {}),
                        **({"rehearsal": "MC_BENCH_BACKEND=gloo: ranks share GPUs, gather staged through the host; "
                                         "timings are NOT a measurement"} if backend != "nccl" and n > 1 else {}),
                        **({"verified_equal_to_single_gpu": verified} if verified is not None else {})},
             "roofline": {"bound": "valu", "kernel": kern, "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_TFLOPS,
-                         "traffic": profiled_traffic(wl, args, n),
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": kernel_ms, "flops_per_unit": flops_per_unit,
                          # HBM is not the bound: the algorithmic bytes are the 16-B storage-buffer entry per pixel
-                         # (+4 B iteration count for Mandelbrot), written once
-                         "hbm": {"algorithmic_bytes": W * rows_local * (16 if wl == "pathtrace" else 20),
-                                 "gbps": W * rows_local * (16 if wl == "pathtrace" else 20) / (kernel_ms * 1e-3) / 1e9,
-                                 "peak_gbps": 8000.0},
+                         # (+4 B iteration count for Mandelbrot), written once per launch
+                         "hbm": {"algorithmic_bytes": alg_bytes, "gbps": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak_gbps": 8000.0},
                          "lane_ops": {"achieved": achieved_tflops * 1e12, "peak": PEAK_LANE_OPS,
                                       "frac": achieved_tflops * 1e12 / PEAK_LANE_OPS,
                                       "note": ("142 = the reference composition's literal flop count; the kernel gets the same "
                                                "bits from ~87 issued instructions (Dekker error term = one fma, exact), "
-                                               "so this fraction may exceed 1") if wl == "mandelbrot_ds" else
+                                               "so this fraction may exceed 1") if (not is_pt and cfg["ds"]) else
                                               ("fast math: hardware transcendentals and a*b+c contraction (toleranced parity); "
-                                               "the strict kernel, reported beside it, forbids both") if wl == "pathtrace" and args.math == "fast"
+                                               "the strict kernel, reported beside it, forbids both") if is_pt and args.math == "fast"
                                               else "parity forbids contraction: one issue slot per flop"}},
         }
 
-    # ---- secondary metric + CPU baseline: rank 0, N = 1 only, outside the timed region ------------------
-    if rank == 0 and n == 1 and not args.no_secondary and wl == "pathtrace":
-        q = B.mandelbrot_params(K1["W"], K1["H"], max_iter=K1["M"])
-        rg = torch.empty((K1["H"], K1["W"], 4), dtype=torch.float32, device="cuda")
-        itr = torch.empty((K1["H"], K1["W"]), dtype=torch.int32, device="cuda")
+    # ---- secondary metric + strict-math leg: rank 0, N = 1, default headline only, outside the timed region ----------
+    if rank == 0 and n == 1 and not args.no_secondary and cfg_name == "K2":
+        k1 = CONFIGS["K1"]
+        q = B.mandelbrot_params(k1["W"], k1["H"], max_iter=k1["M"])
+        rg = torch.empty((k1["H"], k1["W"], 4), dtype=torch.float32, device="cuda")
+        itr = torch.empty((k1["H"], k1["W"]), dtype=torch.int32, device="cuda")
         for _ in range(3):
             ctx.mandelbrot_device(q, rg.data_ptr(), itr.data_ptr(), stream=stream)
         torch.cuda.synchronize()
@@ -278,10 +337,10 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         it64 = itr.to(torch.int64)
-        pi = int(torch.where(it64 < K1["M"], it64 + 1, torch.full_like(it64, K1["M"])).sum().item())
+        pi = int(torch.where(it64 < k1["M"], it64 + 1, torch.full_like(it64, k1["M"])).sum().item())
         tf = pi * FLOPS_PER_PIXEL_ITER_F32 / (ms * 1e-3) / 1e12
         out["secondary"] = {"metric": "Mandelbrot pixel-iters/s", "value": pi / (ms * 1e-3), "unit": "pixel-iters/s",
-                            "workload": f"mandelbrot {K1['W']}x{K1['H']} M{K1['M']} fp32", "pixel_iters": pi, "kernel_ms": ms,
+                            "workload": f"K1: mandelbrot {k1['W']}x{k1['H']} M{k1['M']} fp32", "pixel_iters": pi, "kernel_ms": ms,
                             "roofline": {"bound": "valu", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                                          "frac": tf / PEAK_FP32_TFLOPS, "lane_ops_frac": tf * 1e12 / PEAK_LANE_OPS}}
         if args.math == "fast" and not (args.width or args.height or args.spp):
@@ -300,27 +359,39 @@ def main():
             out["strict_math"] = {"metric": metric, "value": W * H * spp / (sms * 1e-3), "unit": unit, "kernel_ms": sms,
                                   "note": "bit-identical to the CPU oracle (tests/test_gpu_parity.py)"}
 
+    # ---- CPU baseline: rank 0, N = 1, outside the timed region, a bounded sample of the same workload ----------------
     if rank == 0 and n == 1 and not args.no_cpu_baseline:
         O = entry.load_oracle()   # TEST INFRASTRUCTURE, used here only as the timed CPU baseline
         threads = O.hardware_threads()   # CPUs this process may run on: min(affinity, cgroup quota) - 16 on a one-GPU box
-        if wl == "pathtrace":
-            t = time.perf_counter()   # probe, then size the sample for ~10-20 s of CPU work
-            O.pathtrace(W, H, p.spp, math_mode=O.MATH_LIBM, sample_begin=0, sample_end=1, nthreads=threads)
-            probe = time.perf_counter() - t
-            s_spp = int(max(1, min(p.spp, 12.0 / max(probe, 1e-3))))
+        if is_pt:
+            # probe on a band of rows (one oracle row per thread), then size the sample for ~10-20 s of CPU work
+            band = min(H, max(threads, 16))
             t = time.perf_counter()
-            O.pathtrace(W, H, p.spp, math_mode=O.MATH_LIBM, sample_begin=0, sample_end=s_spp, nthreads=threads)
+            O.pathtrace(W, H, p.spp, math_mode=O.MATH_LIBM, sample_begin=0, sample_end=1, row_begin=0, row_end=band, nthreads=threads)
+            per_sample = (time.perf_counter() - t) / (W * band)
+            budget = 12.0
+            if W * H * per_sample <= budget:           # whole image, several samples per pixel
+                s_spp = int(max(1, min(p.spp, budget / (W * H * per_sample))))
+                rows = (0, H)
+            else:                                      # K3-sized image: one sample per pixel over a band of rows
+                s_spp = 1
+                rows = (0, max(threads, int(budget / (W * per_sample))))
+            t = time.perf_counter()
+            O.pathtrace(W, H, p.spp, math_mode=O.MATH_LIBM, sample_begin=0, sample_end=s_spp, row_begin=rows[0], row_end=rows[1],
+                        nthreads=threads)
             cdt = time.perf_counter() - t
-            out["cpu_baseline"] = {"value": W * H * s_spp / cdt, "unit": unit, "cores": threads, "kind": "port",
-                                   "sample": f"samples 0..{s_spp - 1} of {p.spp} over the full {W}x{H} image "
-                                             f"({W * H * s_spp} samples, {cdt:.1f} s)"}
+            nsamp = W * (rows[1] - rows[0]) * s_spp
+            out["cpu_baseline"] = {"value": nsamp / cdt, "unit": unit, "cores": threads, "kind": "port",
+                                   "sample": f"samples 0..{s_spp - 1} of {p.spp} over rows {rows[0]}..{rows[1] - 1} of the "
+                                             f"{W}x{H} image ({nsamp} samples, {cdt:.1f} s)"}
         else:
-            rows = list(range(0, H, 4))   # every 4th row: same interior/exterior mix as the full image
+            stride = 4 if p.max_iter <= 1000 else 64   # every 4th (K1) / 64th (K4) row: same interior/exterior mix as the image
+            rows = list(range(0, H, stride))
             from concurrent.futures import ThreadPoolExecutor
-            view = O.make_view(*(K4_VIEW["centre"] + K4_VIEW["scale"])) if wl == "mandelbrot_ds" else O.REF_VIEW
+            view = O.make_view(*(K4_VIEW["centre"] + K4_VIEW["scale"])) if cfg["ds"] else O.REF_VIEW
 
             def one_row(r):   # ctypes releases the GIL: one oracle row per worker thread
-                itc = O.mandelbrot_iters(W, H, p.max_iter, view=view, precision=int(wl == "mandelbrot_ds"), row_begin=r,
+                itc = O.mandelbrot_iters(W, H, p.max_iter, view=view, precision=int(cfg["ds"]), row_begin=r,
                                          row_end=r + 1, nthreads=1)
                 return O.mandel_pixel_iters(itc, p.max_iter)
 
@@ -329,7 +400,7 @@ def main():
                 tot = sum(ex.map(one_row, rows))
             cdt = time.perf_counter() - t
             out["cpu_baseline"] = {"value": tot / cdt, "unit": unit, "cores": threads, "kind": "port",
-                                   "sample": f"every 4th row of the {W}x{H} image ({tot} pixel-iters, {cdt:.1f} s)"}
+                                   "sample": f"every {stride}th row of the {W}x{H} image ({tot} pixel-iters, {cdt:.1f} s)"}
 
     if rank == 0:
         print(json.dumps(out), flush=True)

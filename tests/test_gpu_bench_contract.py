@@ -24,15 +24,15 @@ def run_bench(args, env_extra=None, launcher=None, timeout=600):
     return json.loads(lines[0])
 
 
-def check_common(d, n, steps, warmup):
+def check_common(d, n, steps, warmup, scaling="weak"):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
     assert d["n_gpus"] == n and d["steps"] == steps and d["warmup"] == warmup
-    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["higher_is_better"] is True and d["scaling"] == scaling and d["vs_baseline"] is None
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"):
         assert k in r, k
     assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["value"] > 0 and d["ms_per_step"] > 0
@@ -72,3 +72,34 @@ def test_two_rank_rehearsal_is_bit_identical_to_one_gpu():
     assert d["config"]["image"] == [900, 1200] and d["config"]["rows_per_gpu"] == 600
     assert d["config"]["verified_equal_to_single_gpu"] is True
     assert "cpu_baseline" not in d                      # rank 0 at N = 1 only
+
+
+def test_baseline_8gpu_configs_run_from_the_driver_command():
+    """BASELINE's 8-GPU configurations are reachable as `bench.py --config K3|K4` (strong scaling: the whole image on N
+    ranks).  K4 at full size on one GPU; K3 at reduced spp (its 4096-spp step is 4e10 samples, ~4 s)."""
+    d = run_bench(["--config", "K4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    check_common(d, 1, 2, 1, scaling="strong")
+    assert d["config"]["baseline_config"] == "K4" and d["config"]["image"] == [7680, 5120]
+    assert d["metric"] == "Mandelbrot pixel-iters/s"
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 41176259776) < 1.0          # the frozen checksum of executed loop bodies
+    d = run_bench(["--config", "K3", "--steps", "1", "--warmup", "1", "--spp", "8"])
+    check_common(d, 1, 1, 1, scaling="strong")
+    assert d["config"]["baseline_config"] == "K3" and d["config"]["image"] == [3840, 2560]
+    assert abs(d["value"] - 3840 * 2560 * 8 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert "one sample" in d["cpu_baseline"]["sample"] or "samples 0.." in d["cpu_baseline"]["sample"]
+
+
+def test_four_rank_rehearsal_strong_scaling_with_per_rank_evidence():
+    """K3 geometry cut down (384 x 250: 32 row blocks, the last one partial -> ranks own 64/64/64/58 rows) over 4 ranks
+    (gloo rehearsal on the one GPU): per-rank rows / devices / kernel times arrive on rank 0, every rank saw world size 4,
+    and the gathered image is bit-identical to the single-GPU render."""
+    launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                "--master-port", "29541"]
+    d = run_bench(["--gpus", "4", "--steps", "1", "--warmup", "1", "--config", "K3", "--spp", "6", "--width", "384", "--height", "250",
+                   "--verify"], env_extra={"MC_BENCH_BACKEND": "gloo"}, launcher=launcher)
+    check_common(d, 4, 1, 1, scaling="strong")
+    c = d["config"]
+    assert c["image"] == [384, 250] and c["world_size"] == 4 and c["verified_equal_to_single_gpu"] is True
+    assert [r["rank"] for r in c["ranks"]] == [0, 1, 2, 3] and all(r["world_size_seen"] == 4 for r in c["ranks"])
+    assert [r["rows"] for r in c["ranks"]] == [64, 64, 64, 58] and sum(r["units_per_step"] for r in c["ranks"]) == 384 * 250 * 6
+    assert all(r["kernel_ms"] > 0 for r in c["ranks"]) and c["gather_ms_rank0"] > 0
