@@ -119,6 +119,25 @@ def test_mandelbrot_f32_iteration_plane_and_buffer(ctx, B, O, W, H, M):
     assert np.array_equal(u8, lut_u8[ref])
 
 
+@pytest.mark.parametrize("precision", ["f32", "ds"])
+def test_mandelbrot_converged_tile_early_out_is_exact(ctx, B, O, precision):
+    """Waves leave the loop once every lane has escaped or provably cycles (mandelbrot.hip, escape_time): the iteration
+    plane must not change.  Views full of interior pixels (cardioid, period-2 bulb, a deep-interior zoom whose orbits
+    reach their fixed point almost at once, a seahorse-valley tile with escaping and cycling lanes side by side), iteration
+    limits around the Brent reference updates and far beyond them, limits that are not multiples of the block length."""
+    ds = precision == "ds"
+    views = [((-0.445, 0.0), (2.34, 2.34)), ((-0.2, 0.0), (0.6, 0.6)), ((-1.0, 0.0), (0.4, 0.4)), ((0.0, 0.0), (1e-3, 1e-3)),
+             ((-0.75, 0.1), (0.05, 0.05)), ((-0.16, 1.0405), (0.02, 0.02))]
+    for (centre, scale), M in zip(views, (4000, 9, 130, 523, 2049, 1000)):
+        W, H = (48, 40) if ds else (96, 80)
+        kw = dict(precision=B.PRECISION_DS) if ds else {}
+        p = B.mandelbrot_params(W, H, max_iter=M, centre=centre, scale=scale, **kw)
+        _, it = ctx.mandelbrot(p, want_rgba=False)
+        ref = O.mandelbrot_iters(W, H, M, view=O.make_view(centre[0], centre[1], scale[0], scale[1]), precision=int(ds))
+        assert np.array_equal(it, ref), (precision, centre, scale, M)
+    assert int((ref == M).sum()) >= 0
+
+
 def test_mandelbrot_other_views_and_colours(ctx, B, O):
     for centre, scale, kc in [((-0.75, 0.1), (0.01, 0.0075), (0.9, 0.1, 0.3, 0.0)), ((0.3, -0.5), (3.0, 2.0), (0.66, 0.3, 0.5, 0.0))]:
         p = B.mandelbrot_params(320, 240, max_iter=300, centre=centre, scale=scale, k_color=kc)
