@@ -83,6 +83,18 @@ def main():
     else:
         print("reference checkout absent: readme_image_block_means.npy not regenerated")
 
+    # the reference's own lodepng (oracle/_ref, compiled from /root/reference where it lies) on the oracle's default
+    # Mandelbrot RGBA8 image: the byte stream INTEGRATION.md route B produces; only its SHA-256 is committed
+    if O.ref_lodepng() is not None:
+        import hashlib
+        _, lut_u8 = O.mandel_lut(128)
+        img = np.ascontiguousarray(lut_u8[O.mandelbrot_iters(256, 256, 128)])
+        png = O.ref_png_encode(img, 256, 256)
+        with open(os.path.join(OUT, "mandelbrot_256_M128_lodepng.sha256"), "w") as f:
+            f.write(hashlib.sha256(png).hexdigest() + "  lodepng::encode(RGBA8 of the oracle's 256x256 M=128 Mandelbrot), %d bytes; "
+                    "made by tests/golden/make_golden.py\n" % len(png))
+        print("wrote mandelbrot_256_M128_lodepng.sha256")
+
 
 if __name__ == "__main__":
     main()

@@ -5,7 +5,7 @@
 //
 // Design (MI355X-first, not a translation of the 32x32 Vulkan workgroup):
 //  * one work-item per pixel; a wave64 owns an 8x8 pixel tile (coherent trip counts, and every
-//    128-B output segment of a row is written whole), a 256-thread block owns 16x16 pixels.
+//    128-B output segment of a row is written whole); one wave per workgroup.
 //  * the escape test is a wave ballot (`v_cmp_* sgpr-pair`), not an exec-mask update: the loop body
 //    is straight-line VALU for U iterations and all bookkeeping (OR of the U ballots, "every lane
 //    done" early-out, iteration counter) runs on the scalar unit.  Per-lane iteration counts are
@@ -213,11 +213,13 @@ __device__ __forceinline__ uint32_t escape_time(State& st, uint32_t max_iter, bo
 }
 
 template <class State, int U>
-__global__ void __launch_bounds__(256) mandelbrot_kernel(MandelArgs a) {
-    // block = 16x16 pixels, wave = 8x8 tile, lane = (lx, ly) inside the tile
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t gx = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t ty = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);   // tile-local row
+__global__ void __launch_bounds__(64) mandelbrot_kernel(MandelArgs a) {
+    // workgroup = one wave = one 8x8 pixel tile, lane = (lx, ly) inside the tile.  Tiles finish anywhere between 1 and
+    // max_iter iterations apart, so the unit the hardware schedules is the tile itself: a 4-wave block would keep its
+    // place on the CU until its slowest tile is through (K1: 0.208 -> 0.200 ms).
+    const uint32_t lane = threadIdx.x;
+    const uint32_t gx = blockIdx.x * 8u + (lane & 7u);
+    const uint32_t ty = blockIdx.y * 8u + (lane >> 3);   // tile-local row
     const uint32_t gy = tile_row_to_storage(ty, a.row_begin, a.row_block, a.row_stride);
     const bool valid = gx < a.W && gy < a.row_end;                            // mandelbrot.comp:27-28
     State st;
@@ -326,7 +328,7 @@ int mandelbrot_launch(mc_context* ctx, const mc_mandelbrot_params* p, void* d_rg
     a.out_iters = (uint32_t*)d_iters;
     a.lut = d_rgba ? (const float4*)ctx->lut.ptr : nullptr;
     const uint32_t rows = tile_rows(p->row_begin, p->row_end, a.row_block, a.row_stride);
-    dim3 grid((p->width + 15u) / 16u, (rows + 15u) / 16u), block(256);
+    dim3 grid((p->width + 7u) / 8u, (rows + 7u) / 8u), block(64);
     if (p->precision == MC_PRECISION_DS) {
         hipLaunchKernelGGL((mandelbrot_kernel<StateDS, 4>), grid, block, 0, s, a);
     } else if (p->flags & MC_MANDEL_FMA) {

@@ -22,7 +22,7 @@ __device__ __forceinline__ uint32_t as_uint(float f) { return __float_as_uint(f)
 
 // ---- IEEE primitives ------------------------------------------------------------------------------
 // hipcc's default for HIP is correctly-rounded fp32 divide and sqrt (-fhip-fp32-correctly-rounded-divide-sqrt);
-// the parity tests (tests/test_device_math.py) verify both against the host bit for bit.
+// the parity tests (tests/test_gpu_parity.py::test_mc_math_bit_exact) verify both against the host bit for bit.
 __device__ __forceinline__ float ieee_div(float a, float b) { return a / b; }
 __device__ __forceinline__ float ieee_sqrt(float a) { return __builtin_sqrtf(a); }
 

@@ -69,7 +69,7 @@ int main(int argc, char* argv[]) {
     const int32_t spp = pos.size() > 0 ? atoi(pos[0]) : 500;                           // samples per pixel
     const uint32_t resy = pos.size() > 1 ? static_cast<uint32_t>(atoi(pos[1])) : 600;  // vertical pixel resolution
     const uint32_t resx = resy * 3 / 2;                                                // horizontal pixel resolution
-    PathtracerApp app = PathtracerApp(resx, resy, spp);
+    PathtracerApp app = PathtracerApp(resx, resy, spp, 16, quiet);
     app.setMathMode(mathMode);
     if (largeSpheres) app.useLargeSphereWalls();
     app.setSpherePrecision(spherePrec);

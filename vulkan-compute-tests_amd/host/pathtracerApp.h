@@ -13,8 +13,11 @@ struct PathtracerApp : public ComputeApp {
         uint32_t samps[2];        // { 0, spp }
     } pushConst;
 
-    // Same signature as the reference (pathtracerApp.h:49).
-    PathtracerApp(const uint32_t resx, const uint32_t resy, const int32_t spp, const uint32_t workgroupSize = 16) {
+    // Same signature as the reference (pathtracerApp.h:49); `quiet` (main.cpp --quiet) only silences the constructor's
+    // "in PathtracerApp ctor" line, which the reference always prints.
+    PathtracerApp(const uint32_t resx, const uint32_t resy, const int32_t spp, const uint32_t workgroupSize = 16,
+                  const bool quiet = false) {
+        setQuiet(quiet);
         this->resx = resx;
         this->resy = resy;
         this->spp = spp;
