@@ -233,6 +233,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_k0, ev_k1)]))
+    sclk_mhz = ctx.measure_clock() if rank == 0 else None   # the clock this box holds under VALU load (boxes differ by >10 %)
     gather_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_k1, ev_g1)])) if n > 1 else 0.0
 
     # ---- units ------------------------------------------------------------------------------------
@@ -294,7 +295,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_name, "baseline_config": cfg_name, "image": [W, H], "rows_per_gpu": rows_local,
                        "tiling": "whole image" if n == 1 else f"interleaved {ROW_BLOCK}-row blocks, RCCL gather to rank 0",
-                       "device": dev_name, "compute_units": cus,
+                       "device": dev_name, "compute_units": cus, "sclk_mhz_under_valu_load": round(sclk_mhz, 1),
                        **({"backend": backend, "world_size": dist.get_world_size(), "ranks": ranks_info,
                            "gather_ms_rank0": round(gather_ms, 4),
                            "gather_note": "kernel end -> gathered + re-assembled on rank 0; includes waiting for the slowest rank"}
@@ -311,6 +312,8 @@ def main():
                          "hbm": {"algorithmic_bytes": alg_bytes, "gbps": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak_gbps": 8000.0},
                          "lane_ops": {"achieved": achieved_tflops * 1e12, "peak": PEAK_LANE_OPS,
                                       "frac": achieved_tflops * 1e12 / PEAK_LANE_OPS,
+                                      # the same against the lane-op rate at the clock this box actually holds under load
+                                      "frac_at_measured_clock": achieved_tflops * 1e12 / (cus * 4 * 32 * sclk_mhz * 1e6),
                                       "note": ("142 = the reference composition's literal flop count; the kernel gets the same "
                                                "bits from ~87 issued instructions (Dekker error term = one fma, exact), "
                                                "so this fraction may exceed 1") if (not is_pt and cfg["ds"]) else

@@ -53,6 +53,11 @@ const char* mc_last_error_detail(void);
 /* Device name / CU count of the context's device (vulkanComputeApp.cpp:163 picks devices[0]). */
 int mc_context_device_info(mc_context* ctx, char* name, size_t name_len, int* compute_units, int* clock_khz);
 
+/* Shader clock (MHz) the device holds with every SIMD busy on fp32 VALU work, measured in-kernel (s_memtime against the
+ * constant 100 MHz s_memrealtime over ~2 ms).  MI355X boxes differ by >10 % here (DVFS), and VALU-issue-bound kernels with
+ * them; bench.py prints it next to every timing so that runs on different boxes can be compared (no reference counterpart). */
+int mc_context_measure_clock(mc_context* ctx, double* sclk_mhz);
+
 /* ---- Mandelbrot: replaces shaders/mandelbrot.comp:21-60 + the dispatch recorded in
  *      MandelbrotApp::createCommandBuffer (src/mandelbrotApp.h:137-147) ----------------------------- */
 enum { MC_PRECISION_F32 = 0, MC_PRECISION_DS = 1 /* two-float, emulateDouble.h.glsl:59-139 */ };

@@ -63,3 +63,12 @@ def test_scene_without_lights_and_with_misses(ctx, B, O):
     ref = O.pathtrace(32, 20, 8, planes=floor, spheres=light, math_mode=O.MATH_MC)
     assert np.array_equal(bits(out), bits(ref))
     assert len(np.unique(ref[..., 0])) > 3
+
+
+def test_clock_probe_reports_a_plausible_shader_clock(ctx):
+    """mc_context_measure_clock: in-kernel s_memtime / s_memrealtime ratio under full VALU load (bench.py prints it so that
+    timings from different boxes can be compared: MI355X devices hold different clocks under load)."""
+    mhz = ctx.measure_clock()
+    assert 1200.0 < mhz < 2500.0, mhz
+    again = ctx.measure_clock()
+    assert abs(again - mhz) / mhz < 0.08

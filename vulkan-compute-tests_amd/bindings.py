@@ -81,6 +81,7 @@ def lib():
         L.mc_context_destroy.argtypes = [vp]
         L.mc_context_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(i32), C.POINTER(i32)]
         L.mc_context_synchronize.argtypes = [vp]
+        L.mc_context_measure_clock.argtypes = [vp, C.POINTER(C.c_double)]
         L.mc_row_block.argtypes = []
         L.mc_row_block.restype = u32
         L.mc_tile_rows.argtypes = [u32, u32, u32, u32]
@@ -215,6 +216,12 @@ class Context:
         cu, clk = C.c_int(0), C.c_int(0)
         _check(lib().mc_context_device_info(self._h, name, 256, C.byref(cu), C.byref(clk)), "mc_context_device_info")
         return name.value.decode(), cu.value, clk.value
+
+    def measure_clock(self):
+        """Shader clock (MHz) under full fp32 VALU load, measured in-kernel."""
+        mhz = C.c_double(0.0)
+        _check(lib().mc_context_measure_clock(self._h, C.byref(mhz)), "mc_context_measure_clock")
+        return mhz.value
 
     def synchronize(self):
         _check(lib().mc_context_synchronize(self._h), "mc_context_synchronize")

@@ -1,5 +1,6 @@
 // C ABI of libmc_compute.so (include/mc_compute.h): context lifecycle, host-buffer entry points,
 // defaults, and the device self-test hooks used by the parity suite.
+#include <algorithm>
 #include <cstring>
 
 #include "ds_arith.h"
@@ -75,6 +76,27 @@ static const float kDefaultSpheres[3 * 12] = {
     (float)1.3,  (float)-1.2, (float)-0.2, (float)0.8, 0, 0, 0, 0, (float).999, (float).999, (float).999, 3,   // glass
     0, (float)(2 * 0.8), 0, (float)0.2, 100, 100, 100, 0, 0, 0, 0, 1,                                            // light
 };
+
+// ---- shader clock under load (mc_context_measure_clock) ------------------------------------------------
+// Every wave runs a dependent fp32 chain for ~`trips` x 64 instructions and stamps s_memtime (shader clock) and
+// s_memrealtime (constant 100 MHz) around it; the ratio is the clock the chip actually holds with every SIMD busy
+// (MI355X_MICROARCH.md, DVFS give-back item 6).  Stamps go to a buffer of their own; nothing else reads them.
+__global__ void __launch_bounds__(256) clock_probe_kernel(unsigned long long* __restrict__ stamps, float* __restrict__ sink, int trips) {
+    float a0 = (float)threadIdx.x, a1 = a0 + 1.0f, a2 = a0 + 2.0f, a3 = a0 + 3.0f;
+    const float b = 1.0000001f, c = 1e-7f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < trips; i++) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) { a0 = a0 * b + c; a1 = a1 * b + c; a2 = a2 * b + c; a3 = a3 * b + c; }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63u) == 0u) {
+        const size_t w = (size_t)blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6);
+        stamps[2 * w] = t1 - t0;
+        stamps[2 * w + 1] = r1 - r0;
+    }
+    if (a0 + a1 + a2 + a3 == 12345.678f) sink[0] = a0;   // keeps the chain alive
+}
 
 // ---- device self-test kernels -----------------------------------------------------------------------
 __global__ void test_math_kernel(int fn, int fast, const float* __restrict__ in, float* __restrict__ out, size_t n) {
@@ -244,6 +266,32 @@ int mc_context_synchronize(mc_context* ctx) {
     MC_HIP_TRY(hipSetDevice(ctx->device));
     MC_HIP_TRY(hipStreamSynchronize(ctx->stream));
     return ctx->check_status();
+}
+
+int mc_context_measure_clock(mc_context* ctx, double* sclk_mhz) {
+    if (!ctx || !sclk_mhz) return MC_ERR_INVALID_ARGUMENT;
+    MC_HIP_TRY(hipSetDevice(ctx->device));
+    const int blocks = ctx->props.multiProcessorCount * 8, waves = blocks * 4;   // 8 waves per SIMD: every CU full
+    DeviceBuffer stamps, sink;
+    struct Release { DeviceBuffer &a, &b; ~Release() { a.release(); b.release(); } } release{stamps, sink};
+    int rc;
+    if ((rc = stamps.reserve(sizeof(unsigned long long) * 2 * waves))) return rc;
+    if ((rc = sink.reserve(256))) return rc;
+    std::vector<unsigned long long> host(2 * (size_t)waves);
+    for (int pass = 0; pass < 2; pass++) {   // pass 0 warms the clock governor up; pass 1 (~2 ms of full-chip VALU work) is read
+        hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (unsigned long long*)stamps.ptr,
+                           (float*)sink.ptr, pass == 0 ? 2000 : 4000);
+        MC_HIP_TRY(hipGetLastError());
+    }
+    MC_HIP_TRY(hipMemcpyAsync(host.data(), stamps.ptr, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    MC_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<double> mhz;
+    for (int w = 0; w < waves; w++)
+        if (host[2 * w + 1]) mhz.push_back(100.0 * (double)host[2 * w] / (double)host[2 * w + 1]);
+    if (mhz.empty()) return MC_ERR_HIP;
+    std::nth_element(mhz.begin(), mhz.begin() + mhz.size() / 2, mhz.end());
+    *sclk_mhz = mhz[mhz.size() / 2];
+    return MC_OK;
 }
 
 int mc_pathtrace_scene_class(const float* planes, uint32_t n_planes, const float* spheres, uint32_t n_spheres,

@@ -535,7 +535,7 @@ template <int S> constexpr uint32_t block_w() { return 2u * WaveTile<S>::w; }
 template <int S> constexpr uint32_t block_h() { return 2u * WaveTile<S>::h; }
 
 template <bool Fast, int NP, int NS, bool Slab, int S, int Prec>
-__global__ void __launch_bounds__(256, 6) pathtrace_kernel(PTArgs a) {
+__global__ void __launch_bounds__(256, Fast ? 6 : 5) pathtrace_kernel(PTArgs a) {
     // dynamic LDS (no static __shared__ in front: the base stays 16-B aligned): [records | emissive list]
     extern __shared__ float lds_dyn[];
     float* lds_obj = lds_dyn;
