@@ -395,6 +395,22 @@ __device__ __forceinline__ int intersect(const SceneArgs& sc, const float* __res
     return (t < kInf) ? id : -1;                                             // :336
 }
 
+// Stages the 12-float records into LDS for the per-lane material fetch and replaces, in that copy only, three slots by
+// values every bounce would otherwise re-derive: [7] (e.w, unused by the shader) = max(max(c.x, c.y), c.z) (:394), [11] =
+// floor(m + 0.5) as a float (:378/:384), and — `emits_in_slot3`, slab kernels, whose intersection code never reads slot 3 of
+// this copy — [3] = 1 if the object emits (any e component non-zero) else 0.  Call with all threads; ends with a barrier.
+__device__ __forceinline__ void stage_records(float* lds_obj, const float* __restrict__ src, uint32_t n_obj, bool emits_in_slot3) {
+    for (uint32_t i = threadIdx.x; i < n_obj * 12u; i += blockDim.x) lds_obj[i] = src[i];
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n_obj; k += blockDim.x) {
+        float* o = lds_obj + 12u * k;
+        o[7] = dm::gmax(dm::gmax(o[8], o[9]), o[10]);
+        o[11] = __builtin_floorf(o[11] + 0.5f);
+        if (emits_in_slot3) o[3] = (o[4] != 0.0f || o[5] != 0.0f || o[6] != 0.0f) ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+}
+
 // One sample: returns accrad (pathTracer.comp:356-449).
 template <bool Fast, int NP, int NS, bool Slab, int Prec>
 __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restrict__ lds_obj,
@@ -431,15 +447,22 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
         const float* obj = lds_obj + 12 * id;                             // per-lane fetch from LDS
         const bool is_sphere = id >= np;
         v3 geo{obj[0], obj[1], obj[2]};
-        v3 emi{obj[4], obj[5], obj[6]};
         v3 col{obj[8], obj[9], obj[10]};
-        int mat = (int)__builtin_floorf(obj[11] + 0.5f);                  // :378/:384
+        // per-object values derived once per block while the records are staged into LDS (stage_records): the same
+        // fp32 operations on the same operands, so the same values as evaluating them here at every bounce
+        const int mat = (int)obj[11];                                     // = int(floor(m + 0.5)), :378/:384
+        const float p = obj[7];                                           // = max(max(c.x, c.y), c.z), :394
         v3 n = is_sphere ? normalize<Fast>(x - geo) : geo;                // :381/:387
         v3 nl = dot(n, rd) < 0.0f ? n : -n;                               // :390
-        accrad = accrad + (accmat * emi) * emissive;                      // :391
+        // :391 accrad += accmat * e * emissive.  For an object without emission (e = +-0) the product is a zero and
+        // accrad (never -0: it starts at +0 and only receives sums) is unchanged, so the nine operations are skipped when no
+        // lane of the wave hit an emitter — almost always (slab kernels; the flag sits in the record's unused slot 3).
+        if (!Slab || __ballot(obj[3] != 0.0f) != 0ull) {
+            v3 emi{obj[4], obj[5], obj[6]};
+            accrad = accrad + (accmat * emi) * emissive;
+        }
         accmat = accmat * col;                                            // :392
         v3 rnd = rand01(gx, gy, samp * a.max_depth + depth);              // :393
-        float p = dm::gmax(dm::gmax(col.x, col.y), col.z);               // :394
         if (depth > 5) {                                                  // :395
             if (rnd.z >= p) break;                                        // :396
             accmat = divs<Fast>(accmat, p);                               // :397
@@ -541,13 +564,12 @@ __global__ void __launch_bounds__(256, Fast ? 6 : 5) pathtrace_kernel(PTArgs a) 
     float* lds_obj = lds_dyn;
     const uint32_t count = (a.scene.n_planes + a.scene.n_spheres) * 12u;
     uint32_t* lds_emissive = reinterpret_cast<uint32_t*>(lds_dyn + count);
-    if (NP < 0) {   // generic: stage from the device buffer
-        for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) lds_obj[i] = a.scene.d_obj[i];
+    if (NP < 0) {   // generic: stage from the device buffer (its intersection loops read this copy too: slot 3 stays)
         for (uint32_t i = threadIdx.x; i < a.scene.n_emissive; i += blockDim.x) lds_emissive[i] = a.scene.d_emissive[i];
+        stage_records(lds_obj, a.scene.d_obj, a.scene.n_planes + a.scene.n_spheres, false);
     } else {        // specialised: stage the kernel-argument copy for the per-lane material fetch
-        for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) lds_obj[i] = a.scene.obj[i];
+        stage_records(lds_obj, a.scene.obj, a.scene.n_planes + a.scene.n_spheres, Slab);
     }
-    __syncthreads();
     constexpr uint32_t TW = WaveTile<S>::w, TH = WaveTile<S>::h;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t j = lane % (uint32_t)S;          // sample slot of this lane within its pixel

@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(64 * NW, 6) pathtrace_regroup_kernel(PTArgs a)
     const float* lds_obj = sh.obj;
 
     // ---- start-up (the only barrier) ----
-    for (uint32_t i = threadIdx.x; i < (NP + NS) * 12u; i += 64u * NW) sh.obj[i] = sc.obj[i];
+    stage_records(sh.obj, sc.obj, NP + NS, true);
     for (uint32_t i = threadIdx.x; i < 2u * Q; i += 64u * NW) sh.seq[i] = i & (Q - 1u);   // slot s is first written by ticket s
     for (uint32_t i = threadIdx.x; i < G::WIN; i += 64u * NW) sh.ring_tag[i] = 0u;         // lap 0 expects 1
     if (threadIdx.x == 0) {
@@ -475,15 +475,17 @@ __global__ void __launch_bounds__(64 * NW, 6) pathtrace_regroup_kernel(PTArgs a)
                 const float* obj = lds_obj + 12 * id;                         // per-lane fetch from LDS
                 const bool is_sphere = id >= NP;
                 v3 geo{obj[0], obj[1], obj[2]};
-                v3 emi{obj[4], obj[5], obj[6]};
                 v3 col{obj[8], obj[9], obj[10]};
-                const int mat = (int)__builtin_floorf(obj[11] + 0.5f);        // :378/:384
+                const int mat = (int)obj[11];                                 // :378/:384, derived in stage_records
+                const float p = obj[7];                                       // :394, derived in stage_records
                 v3 n = is_sphere ? normalize<Fast>(x - geo) : geo;            // :381/:387
                 v3 nl = dot(n, rd) < 0.0f ? n : -n;                           // :390
-                P.accrad = P.accrad + (P.accmat * emi) * emissive;            // :391
+                if (__ballot(obj[3] != 0.0f) != 0ull) {                       // :391 (skipped when no lane hit an emitter)
+                    v3 emi{obj[4], obj[5], obj[6]};
+                    P.accrad = P.accrad + (P.accmat * emi) * emissive;
+                }
                 P.accmat = P.accmat * col;                                    // :392
                 v3 rnd = rand01(gx, gy, samp * a.max_depth + depth);       // :393
-                float p = dm::gmax(dm::gmax(col.x, col.y), col.z);           // :394
                 if (depth > 5u) {                                             // :395
                     if (rnd.z >= p) fin = true;                               // :396
                     else P.accmat = divs<Fast>(P.accmat, p);                  // :397
