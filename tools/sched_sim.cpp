@@ -53,7 +53,7 @@ struct Path {
     int max_depth;
 };
 
-struct Tile { std::vector<std::vector<uint8_t>> samples; };   // [pixel * spp + s]
+struct Tile { std::vector<std::vector<uint8_t>> samples; std::vector<uint32_t> gx, gy; };   // [pixel * spp + s]
 
 struct Stats {
     double cost = 0, useful = 0;          // issued wave-instructions, lane-weighted useful share (x64)
@@ -253,6 +253,69 @@ void sim_twoslot(const Tile& t, int pix0, int spp, int max_depth, const Cost& c,
     st.cost += c.commit_item * total_items;
 }
 
+// ---------------------------------------------------------------- rounds kernel with samples SORTED by path length
+// Within a window of `window` consecutive samples of each pixel the samples are traced in order of (predicted) path length,
+// 16 per pixel and round, so that a round's lanes finish together; the ordered fold then needs the window's results in
+// LDS.  noise = 0: the true length (an oracle no kernel has): 1.14x at a 64-sample window, 1.22x over all 500.  noise < 0:
+// the predictor a kernel could afford — Russian roulette's own random numbers, "terminates at the first depth >= 6 whose
+// rnd.z >= -noise" — is right for 68 % of the samples and buys NOTHING (1.00x): one mispredicted long path among the 64
+// lanes keeps the whole round alive, and a guaranteed bound (rnd.z >= 0.999, the spheres' survival probability) almost
+// never triggers.  Idea rejected on the simulator, before any kernel was written.
+void sim_sorted_rounds(const Tile& t, int pixels, int spp, int max_depth, const Cost& c, int window, double noise, unsigned seed, Stats& st) {
+    std::mt19937 rng(seed);
+    std::uniform_real_distribution<double> U(0.0, 1.0);
+    for (int p0 = 0; p0 < pixels; p0 += 4) {
+        for (int w0 = 0; w0 < spp; w0 += window) {
+            const int wn = std::min(window, spp - w0);
+            // per pixel: order of the window's samples by key
+            std::vector<int> order[4];
+            for (int pp = 0; pp < 4; pp++) {
+                std::vector<std::pair<double, int>> keys;
+                for (int k = 0; k < wn; k++) {
+                    const auto& ev = t.samples[(size_t)(p0 + pp) * spp + w0 + k];
+                    double len = (double)ev.size();
+                    if (noise < 0.0) {   // the predictor a kernel can afford: Russian roulette's own random numbers (pathTracer.comp:393-396)
+                        len = (double)max_depth;
+                        for (int d = 6; d < max_depth; d++) {
+                            oracle::v3 r = oracle::rand01<oracle::PlainPolicy>(t.gx[p0 + pp], t.gy[p0 + pp], (uint32_t)(w0 + k) * (uint32_t)max_depth + (uint32_t)d);
+                            if (r.z >= -noise) { len = d + 1; break; }
+                        }
+                        keys.push_back({len, k});
+                    } else
+                    keys.push_back({len + noise * (U(rng) - 0.5) * 6.0, k});
+                }
+                std::sort(keys.begin(), keys.end());
+                for (auto& kv : keys) order[pp].push_back(kv.second);
+            }
+            for (int base = 0; base < wn; base += 16) {
+                const std::vector<uint8_t>* ev[64]; int pos[64], alive[64];
+                int n = 0;
+                for (int l = 0; l < 64; l++) {
+                    int pp = l / 16, k = base + l % 16;
+                    alive[l] = k < wn;
+                    ev[l] = alive[l] ? &t.samples[(size_t)(p0 + pp) * spp + w0 + order[pp][k]] : nullptr;
+                    pos[l] = 0; n += alive[l];
+                }
+                st.cost += c.cam + c.fold_round + 24; st.n_samples += n;   // + deposit / key bookkeeping
+                for (int depth = 0; depth < max_depth; depth++) {
+                    int na = 0, nd = 0, ng = 0, nm = 0;
+                    for (int l = 0; l < 64; l++) {
+                        if (!alive[l]) continue;
+                        na++;
+                        if (pos[l] >= (int)ev[l]->size()) { alive[l] = 0; continue; }
+                        int e = (*ev[l])[pos[l]++];
+                        if (e == 0) alive[l] = 0; else if (e == 1) nd++; else if (e == 2) nm++; else ng++;
+                    }
+                    if (!na) break;
+                    st.iters += 1;
+                    st.cost += c.ip + (nd ? c.d : 0) + (ng ? c.g : 0) + (nm ? c.m : 0);
+                    st.useful += (na * c.ip + nd * c.d + ng * c.g + nm * c.m) / 64.0;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -271,6 +334,8 @@ int main(int argc, char** argv) {
     for (auto& t : tiles) {
         int x0 = (rng() % (W / 8)) * 8, y0 = (rng() % (H / 4)) * 4;
         t.samples.resize((size_t)pixels * spp);
+        t.gx.resize(pixels); t.gy.resize(pixels);
+        for (int p = 0; p < pixels; p++) { t.gx[p] = x0 + (p % 16) % 4 + 4 * (p / 16); t.gy[p] = y0 + (p % 16) / 4; }
         for (int p = 0; p < pixels; p++)
             for (int s = 0; s < spp; s++) {
                 auto& ev = t.samples[(size_t)p * spp + s];
@@ -304,6 +369,13 @@ int main(int argc, char** argv) {
                n.cfg.waves, n.cfg.window, n.cfg.s_batch_min, n.cfg.dq_cap, n.cfg.sq_cap, s.cost / s.n_samples,
                (base.cost / base.n_samples) / (s.cost / s.n_samples), s.useful / s.cost, s.max_dq, s.max_sq, s.max_window, s.stall_lane_iters / 64);
     }
+    for (int win : {32, 64, 128, 256, 500})
+        for (double noise : {0.0, -0.70, -0.75, -0.80, -0.85}) {
+            Stats s;
+            for (auto& t : tiles) sim_sorted_rounds(t, pixels, spp, max_depth, c, win, noise, 7, s);
+            printf("sorted rounds window=%3d noise=%.1f : cost/sample %7.1f (%.3fx)  lanes %.3f  iters/64samples %.2f\n", win, noise,
+                   s.cost / s.n_samples, (base.cost / base.n_samples) / (s.cost / s.n_samples), s.useful / s.cost, s.iters * 64.0 / s.n_samples);
+        }
     for (int ov : {10, 20})
         for (int win : {64, 128, 256, 512})
             for (int thr : {24, 32, 40, 48}) {
