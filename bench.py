@@ -89,6 +89,23 @@ def profiled_traffic(cfg_name, args, n):
     return None, None
 
 
+def lavapipe_probe():
+    """BASELINE.md §3 plan 1 asks for the reference's own Vulkan build on lavapipe as the CPU baseline when the tooling exists.
+    It needs a Vulkan loader, a lavapipe ICD, a GLSL compiler AND the reference checkout; the GPU box receives only this
+    repository, so the probe documents what is missing and the baseline stays the oracle port (kind "port")."""
+    import ctypes.util
+    import glob
+    import shutil
+    found = {
+        "libvulkan": bool(ctypes.util.find_library("vulkan")),
+        "lavapipe_icd": bool(glob.glob("/usr/share/vulkan/icd.d/lvp_icd*.json") + glob.glob("/etc/vulkan/icd.d/lvp_icd*.json")),
+        "glsl_compiler": bool(shutil.which("glslangValidator") or shutil.which("glslc")),
+        "reference_checkout": os.path.isdir(os.environ.get("MC_REFERENCE_DIR", "/root/reference")),
+    }
+    found["usable"] = all(found.values())
+    return found
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -405,6 +422,8 @@ def main():
             out["cpu_baseline"] = {"value": tot / cdt, "unit": unit, "cores": threads, "kind": "port",
                                    "sample": f"every {stride}th row of the {W}x{H} image ({tot} pixel-iters, {cdt:.1f} s)"}
 
+    if rank == 0 and "cpu_baseline" in out:
+        out["cpu_baseline"]["lavapipe_probe"] = lavapipe_probe()   # all four must exist for kind "reference"; they do not here
     if rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()
