@@ -215,6 +215,11 @@ int mc_multi_pathtrace_render_rgba8(mc_multi* m, const mc_pathtrace_params* p, c
 /* fn: 0 mc_sin, 1 mc_cos, 2 mc_log2, 3 mc_exp2, 4 pow(x,0.45), 5 inversesqrt, 6 sqrt, 7 1/x,
  * 8/9 sin/cos via the fused mc_sincos; fast=1 evaluates the MC_PT_MATH_FAST variants instead. */
 int mc_test_math(mc_context* ctx, int fn, int fast, const float* in, float* out, size_t n);
+/* Strict fn 5 / 6 / 7 (and the guarded short reciprocal) over EVERY fp32 bit pattern first_bits .. first_bits+count-1, compared on
+ * the device with the compiler's IEEE expansion: *mismatches (NaN == NaN), *checksum = sum of (result_bits ^ (bits * 0x9E3779B1))
+ * mod 2^64 for a host-side comparison, *first_mismatch = lowest offending pattern (0xffffffff if none). */
+int mc_test_math_sweep(mc_context* ctx, int fn, uint32_t first_bits, uint64_t count, uint64_t* mismatches, uint64_t* checksum,
+                       uint32_t* first_mismatch);
 /* rand01 (pathTracer.comp:107-110) over n keys (x,y,z) -> 3 floats each. */
 int mc_test_rand01(mc_context* ctx, const uint32_t* xyz, float* out, size_t n);
 /* two-float primitives (emulateDouble.h.glsl): op 0 ds_add, 1 ds_sub, 2 ds_mul, 3 ds_compare, 4 ds_sqrt(a), 5 df64_add,

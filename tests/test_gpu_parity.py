@@ -89,6 +89,25 @@ def test_ieee_div_sqrt_bit_exact(ctx):
         assert np.array_equal(bits(ctx.test_math("rsqrt", x)), bits(np.float32(1.0) / np.sqrt(x)))
 
 
+@pytest.mark.parametrize("fn", ["sqrt", "rsqrt", "rcp"])
+def test_short_forms_exhaustive(ctx, fn):
+    """The strict path tracer's sqrt / inversesqrt take 5- and 8-instruction short forms inside [2^-100, 2^100) and the
+    compiler's IEEE expansions elsewhere (csrc/mc_math.h).  Correct rounding of the short forms rests on enumeration:
+    ALL 2^32 bit patterns (zero, denormals, inf, NaN, negatives included) against the IEEE expansion on the device, and
+    the whole positive window, pattern by pattern, against the host's IEEE arithmetic through a position-keyed checksum."""
+    bad, _, first = ctx.test_math_sweep(fn, 0, 1 << 32)
+    assert bad == 0, (fn, bad, hex(first))
+    lo, hi = 0x0D800000, 0x71800000                     # 2^-100 .. 2^100: where the short forms run
+    _, chk, _ = ctx.test_math_sweep(fn, lo, hi - lo)
+    want = 0
+    for a in range(lo, hi, 1 << 24):
+        u = np.arange(a, min(a + (1 << 24), hi), dtype=np.uint32)
+        x = u.view(np.float32)
+        r = {"sqrt": lambda: np.sqrt(x), "rsqrt": lambda: np.float32(1.0) / np.sqrt(x), "rcp": lambda: np.float32(1.0) / x}[fn]()
+        want += int((r.view(np.uint32) ^ (u * np.uint32(0x9E3779B1))).astype(np.uint64).sum(dtype=np.uint64))
+    assert chk == want % (1 << 64), fn
+
+
 def test_fast_math_within_a_few_ulp(ctx):
     x = np.random.default_rng(6).uniform(1e-3, 1e3, 100000).astype(np.float32)
     for fn, ref in (("sqrt", np.sqrt(x.astype(np.float64))), ("rcp", 1.0 / x.astype(np.float64)),

@@ -103,6 +103,8 @@ def lib():
         L.mc_multi_mandelbrot_render.argtypes = [vp, C.POINTER(MandelbrotParams), vp, vp]
         L.mc_multi_pathtrace_render.argtypes = [vp, C.POINTER(PathtraceParams), vp, u32, vp, u32, vp]
         L.mc_test_math.argtypes = [vp, i32, i32, vp, vp, C.c_size_t]
+        L.mc_test_math_sweep.argtypes = [vp, i32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_uint32)]
         L.mc_test_rand01.argtypes = [vp, vp, vp, C.c_size_t]
         L.mc_test_ds_op.argtypes = [vp, i32, vp, vp, vp, C.c_size_t]
         _lib = L
@@ -282,6 +284,14 @@ class Context:
         out = np.empty_like(x)
         _check(lib().mc_test_math(self._h, code, int(fast), _ptr(x), _ptr(out), x.size), "mc_test_math")
         return out
+
+    def test_math_sweep(self, fn, first_bits, count):
+        """(mismatches vs the IEEE expansion, checksum, first mismatching pattern) over `count` consecutive bit patterns."""
+        code = {"rsqrt": 5, "sqrt": 6, "rcp": 7}[fn]
+        bad, chk, first = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
+        _check(lib().mc_test_math_sweep(self._h, code, first_bits, count, C.byref(bad), C.byref(chk), C.byref(first)),
+               "mc_test_math_sweep")
+        return bad.value, chk.value, first.value
 
     def test_rand01(self, xyz):
         k = np.ascontiguousarray(xyz, np.uint32).reshape(-1, 3)

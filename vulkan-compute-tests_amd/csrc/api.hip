@@ -498,6 +498,50 @@ int mc_test_math(mc_context* ctx, int fn, int fast, const float* in, float* out,
                     n, fn, fast);
 }
 
+// Every bit pattern first_bits .. first_bits + count - 1: strict device function vs the compiler's IEEE expansion.
+__global__ void test_math_sweep_kernel(int fn, uint32_t first_bits, unsigned long long count, unsigned long long* res) {
+    unsigned long long bad = 0, sum = 0;
+    uint32_t first_bad = 0xffffffffu;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t u = first_bits + (uint32_t)i;
+        const float x = dm::as_float(u);
+        float got, ref;
+        switch (fn) {
+            case 5: got = dm::inversesqrt<false>(x); ref = dm::ieee_div(1.0f, dm::ieee_sqrt(x)); break;
+            case 6: got = dm::fsqrt<false>(x); ref = dm::ieee_sqrt(x); break;
+            default: got = dm::in_short_window(x) ? dm::rcp_short(x) : dm::ieee_div(1.0f, x); ref = dm::ieee_div(1.0f, x); break;
+        }
+        const uint32_t gb = dm::as_uint(got), rb = dm::as_uint(ref);
+        if (gb != rb && !(got != got && ref != ref)) { bad++; first_bad = first_bad < u ? first_bad : u; }
+        sum += (unsigned long long)(gb ^ (u * 0x9E3779B1u));
+    }
+    atomicAdd(&res[0], bad);
+    atomicAdd(&res[1], sum);
+    atomicMin(&res[2], (unsigned long long)first_bad);
+}
+
+int mc_test_math_sweep(mc_context* ctx, int fn, uint32_t first_bits, uint64_t count, uint64_t* mismatches, uint64_t* checksum,
+                       uint32_t* first_mismatch) {
+    if (!ctx || (fn != 5 && fn != 6 && fn != 7) || !count || count > (1ull << 32) || !mismatches) return MC_ERR_INVALID_ARGUMENT;
+    MC_HIP_TRY(hipSetDevice(ctx->device));
+    DeviceBuffer res;
+    struct Release { DeviceBuffer& b; ~Release() { b.release(); } } release{res};
+    if (int rc = res.reserve(3 * sizeof(unsigned long long))) return rc;
+    const unsigned long long init[3] = {0ull, 0ull, ~0ull};
+    MC_HIP_TRY(hipMemcpy(res.ptr, init, sizeof init, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(test_math_sweep_kernel, dim3(256 * 16), dim3(256), 0, ctx->stream, fn, first_bits,
+                       (unsigned long long)count, (unsigned long long*)res.ptr);
+    MC_HIP_TRY(hipGetLastError());
+    unsigned long long out[3];
+    MC_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    MC_HIP_TRY(hipMemcpy(out, res.ptr, sizeof out, hipMemcpyDeviceToHost));
+    *mismatches = out[0];
+    if (checksum) *checksum = out[1];
+    if (first_mismatch) *first_mismatch = (uint32_t)out[2];
+    return MC_OK;
+}
+
 int mc_test_rand01(mc_context* ctx, const uint32_t* xyz, float* out, size_t n) {
     if (!ctx || !xyz || !out || !n) return MC_ERR_INVALID_ARGUMENT;
     return run_test(ctx, xyz, n * 12, nullptr, 0, out, n * 12,

@@ -26,16 +26,39 @@ __device__ __forceinline__ uint32_t as_uint(float f) { return __float_as_uint(f)
 __device__ __forceinline__ float ieee_div(float a, float b) { return a / b; }
 __device__ __forceinline__ float ieee_sqrt(float a) { return __builtin_sqrtf(a); }
 
+// Short forms of the correctly rounded sqrt and reciprocal for arguments in [2^-100, 2^100): no operand scaling, no
+// special-case fix-up, so 5 and 3 instructions (one transcendental each) instead of the compiler's 16 and 11.  Correct rounding is a property of the
+// gfx950 v_sqrt/v_rsq/v_rcp seeds, established by enumeration, not by argument: tools/exact_math_exhaustive.hip and
+// tests/test_gpu_parity.py::test_short_forms_exhaustive compare EVERY fp32 bit pattern with the IEEE expansions
+// (sqrt clean for 2^-102 <= x < 2^128, 1/x for 2^-126 <= x < 2^126; profiles/r02_exact_math_exhaustive.txt).
+// Outside the window — zero, denormals, inf, NaN, negatives — the wave takes the compiler's expansion, so the
+// functions are correctly rounded everywhere.  The test is wave-wide (one compare, one scalar branch).
+__device__ __forceinline__ bool in_short_window(float x) { return (as_uint(x) - 0x0D800000u) < 0x64000000u; }   // 2^-100 <= x < 2^100
+__device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }            // over the active lanes
+__device__ __forceinline__ float sqrt_short(float x) {
+    float y = __builtin_amdgcn_rsqf(x);                      // the one transcendental
+    float g = x * y;                                         // sqrt(x) within ~1.5 ulp
+    float d = __builtin_fmaf(-g, g, x);                      // exact residual
+    return __builtin_fmaf(d, 0.5f * y, g);
+}
+__device__ __forceinline__ float rcp_short(float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    float e = __builtin_fmaf(-b, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+
 template <bool Fast> __device__ __forceinline__ float fdiv(float a, float b) {
     if (Fast) return a * __builtin_amdgcn_rcpf(b);
     return ieee_div(a, b);
 }
 template <bool Fast> __device__ __forceinline__ float fsqrt(float a) {
     if (Fast) return __builtin_amdgcn_sqrtf(a);
+    if (wave_all(in_short_window(a))) return sqrt_short(a);
     return ieee_sqrt(a);
 }
 template <bool Fast> __device__ __forceinline__ float inversesqrt(float a) {
     if (Fast) return __builtin_amdgcn_rsqf(a);
+    if (wave_all(in_short_window(a))) return rcp_short(sqrt_short(a));   // sqrt in [2^-50, 2^50): inside rcp_short's window
     return ieee_div(1.0f, ieee_sqrt(a));
 }
 

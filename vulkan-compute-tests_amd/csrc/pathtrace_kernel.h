@@ -313,6 +313,37 @@ __device__ __forceinline__ int intersect_slab(const HotSlab& h, v3 o, v3 d, floa
     return (t < h.inf) ? id : -1;                                            // :336
 }
 
+// Shadow ray of next-event estimation against the three spheres only (slab scenes whose walls can never win, see
+// intersect()): "is sphere `li` the nearest hit?" (pathTracer.comp:420) without carrying t and id through the loop.
+// The reference keeps a later candidate only if it is STRICTLY nearer, so sphere li wins iff its root dd_li is finite,
+// strictly below every root of the spheres before it and not above any root of the spheres after it.  dd_k is the value the
+// loop assigns for sphere k (:319-327), 1e20 when there is none.  Same comparisons on the same values: exact.
+template <bool Fast>
+__device__ __forceinline__ bool shadow_reaches_sphere(const HotSlab& h, v3 o, v3 d, int li) {
+    MC_PT_DECISION_FP
+    float dd[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        v3 oc = v3{h.c[i][0], h.c[i][1], h.c[i][2]} - o;                     // :317
+        float b = dot(oc, d);                                                // :318
+        float det = (b * b - dot(oc, oc)) + h.r2[i];
+        float r = h.inf;
+        if (!(det < 0.0f)) {                                                 // :319
+            float sq = dm::fsqrt<Fast>(det);
+            r = b - sq;                                                      // :322,324
+            if (r <= h.eps) {                                                // :325
+                r = b + sq;                                                  // :323,326
+                if (r <= h.eps) r = h.inf;                                   // :327
+            }
+        }
+        dd[i] = r;
+    }
+    // li is wave-uniform (the NEE loop index): scalar branches
+    if (li == 2) return dd[2] < dd[0] && dd[2] < dd[1] && dd[2] < h.inf;
+    if (li == 1) return dd[1] < dd[0] && !(dd[2] < dd[1]) && dd[1] < h.inf;
+    return !(dd[1] < dd[0]) && !(dd[2] < dd[0]) && dd[0] < h.inf;
+}
+
 // intersect — pathTracer.comp:112-131 + :316-341.  Returns the hit object id (planes 0..NP-1, spheres
 // NP..NP+NS-1) or -1, and the ray parameter.  NP/NS < 0 select run-time counts; `obj` is the record array the
 // loops read with wave-uniform indices: the kernel-argument copy (SGPR operands) for the specialised kernels,
@@ -489,10 +520,14 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 dm::sincos_angle<Fast>(phi, rnd.y, sphi, cphi);
                 v3 l = normalize<Fast>(((su * cphi) * sin_a + (sv * sphi) * sin_a) + sw * cos_a);   // :413
                 float tne;
-                int idne;                                                 // :420 shadow ray
-                if constexpr (Slab) idne = intersect_slab<Fast>(hot, x, l, tne, sc.nee_skip_planes != 0u);
-                else idne = intersect<Fast, NP, NS, Slab, Prec>(sc, uobj, x, l, tne, false);
-                if (idne == np + i) {
+                bool reached;                                             // :420 shadow ray: is the nearest hit sphere i?
+                if constexpr (Slab) {
+                    if (sc.nee_skip_planes != 0u) reached = shadow_reaches_sphere<Fast>(hot, x, l, i);
+                    else reached = intersect_slab<Fast>(hot, x, l, tne, false) == np + i;
+                } else {
+                    reached = intersect<Fast, NP, NS, Slab, Prec>(sc, uobj, x, l, tne, false) == np + i;
+                }
+                if (reached) {
                     MC_REGION(4);   // shadow ray reached the light
                     float omega = (2.0f * kPi) * (1.0f - cos_a_max);      // :421
                     accrad = accrad + ((divs<Fast>(accmat, kPi) * dm::gmax(dot(l, nl), 0.0f)) * le) * omega;   // :422

@@ -412,8 +412,9 @@ __global__ void __launch_bounds__(64 * NW, 6) pathtrace_regroup_kernel(PTArgs a)
                 dm::sincos_angle<Fast>(phi, P.ry, sphi, cphi);
                 v3 l = normalize<Fast>(((su * cphi) * sin_a + (sv * sphi) * sin_a) + sw * cos_a);   // :413
                 float tne;
-                int idne = intersect_slab<Fast>(hot, x, l, tne, sc.nee_skip_planes != 0u);   // :420 shadow ray
-                if (idne == NP + i) {
+                const bool reached = sc.nee_skip_planes != 0u ? shadow_reaches_sphere<Fast>(hot, x, l, i)   // :420 shadow ray
+                                                               : intersect_slab<Fast>(hot, x, l, tne, false) == NP + i;
+                if (reached) {
                     float omega = (2.0f * kPi) * (1.0f - cos_a_max);          // :421
                     P.accrad = P.accrad + ((divs<Fast>(P.accmat, kPi) * dm::gmax(dot(l, nl), 0.0f)) * le) * omega;   // :422
                 }
