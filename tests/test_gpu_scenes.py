@@ -133,3 +133,20 @@ def test_shadow_ray_plane_skip_with_two_lights_and_mirror_walls(ctx, B, O):
     for flags in (0, B.pt_force_s(4), B.pt_force_s(16)):
         out = ctx.pathtrace(B.pathtrace_params(W, H, spp, flags=flags), planes=planes, spheres=spheres)
         assert np.array_equal(bits(out), bits(ref)), flags
+
+
+@pytest.mark.parametrize("which,code", [("sphere", 4.0), ("sphere", 0.0), ("sphere", -2.0), ("wall", 7.0), ("wall", 0.4)])
+def test_unknown_material_codes_keep_their_ray(ctx, B, O, which, code):
+    """A material code other than 1, 2, 3 matches none of pathTracer.comp:400-448: the ray is left as it was and the same
+    intersection repeats at every later depth (colour multiplied again, Russian roulette drawn again).  The slab kernels carry
+    |c - origin|^2 with the ray and must not advance it to the hit point for such an object."""
+    planes, spheres = _box_scene(O)
+    if which == "sphere":
+        spheres[0, 11] = code
+    else:
+        planes[2, 11] = code
+    W, H, spp = 40, 28, 9
+    ref = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC)
+    for flags in (0, B.pt_force_s(1), B.pt_force_s(16), B.PT_GENERIC_KERNEL):
+        out = ctx.pathtrace(B.pathtrace_params(W, H, spp, flags=flags), planes=planes, spheres=spheres)
+        assert np.array_equal(bits(out), bits(ref)), (which, code, flags)

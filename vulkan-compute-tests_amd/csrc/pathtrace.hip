@@ -151,6 +151,11 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
             if (h_dot(e, e) > 0.0f) a.scene.emissive_mask |= 1u << i;
         }
         a.scene.nee_skip_planes = lights_inside_box(a.scene, spheres, n_spheres, a.cam_o, a.lc) ? 1u : 0u;
+        a.scene.materials_known = 1u;
+        for (uint32_t i = 0; i < n_planes + n_spheres; i++) {
+            const float m = floorf(a.scene.obj[12 * i + 11] + 0.5f);          // the kernel's int(floor(m + 0.5)), :378/:384
+            if (!(m == 1.0f || m == 2.0f || m == 3.0f)) a.scene.materials_known = 0u;
+        }
     } else {      // any other scene: device buffer [records | emissive sphere indices], staged into LDS by the kernel
         std::vector<float> host((size_t)(n_planes + n_spheres) * 12 + n_spheres);
         if (n_planes) std::memcpy(host.data(), planes, sizeof(float) * 12 * n_planes);
@@ -188,10 +193,7 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
     // shader re-trace an unchanged ray, which only the round-synchronous loop reproduces) within its packed-field limits.
     bool regroup_ok = slab && prec == 0 && p->max_depth <= 63u && p->width < 65536u && p->height <= 65536u &&
                       (p->sample_end - p->sample_begin) < (1u << 20);
-    for (uint32_t i = 0; regroup_ok && i < n_planes + n_spheres; i++) {
-        const float m = floorf((i < n_planes ? planes[12 * i + 11] : spheres[12 * (i - n_planes) + 11]) + 0.5f);
-        if (!(m == 1.0f || m == 2.0f || m == 3.0f)) regroup_ok = false;
-    }
+    regroup_ok = regroup_ok && a.scene.materials_known != 0u;
     // Never the default: measured slower than the round-synchronous kernels.  The kernel is compiled only
     // into the diagnostic library (make regroup, -DMC_PT_WITH_REGROUP); the shipped library answers MC_ERR_UNSUPPORTED.
     if (p->flags & MC_PT_KERNEL_REGROUP) {

@@ -56,6 +56,9 @@ struct SceneArgs {
     // its light (closed box, camera inside, every emissive sphere inside with a margin — pathtrace.hip,
     // lights_inside_box): the shadow `intersect` then skips the three slab tests.  Exact, see intersect().
     uint32_t nee_skip_planes;
+    // Slab kernels: non-zero when every object's material code int(floor(m + 0.5)) is 1, 2 or 3, i.e. every bounce continues
+    // from its hit point.  Any other code leaves the ray untouched (:400-448 match nothing) and the same ray is traced again.
+    uint32_t materials_known;
     float obj[(kMaxPlanes + kMaxSpheres) * 12];
     float r2[kMaxSpheres];
     // slab form of axis-aligned planes (valid only for the Slab kernels): per axis the plane whose normal
@@ -280,7 +283,8 @@ struct HotSlab {
 // round-to-nearest, and (-n) / (-d) = n / d (IEEE divide; v_rcp_f32 is odd, tested).  So both cases are
 // (W - o[a]) / d[a] with W = pos ? w_pos : -w_neg: one select and one subtraction instead of two additions and a select.
 template <bool Fast>
-__device__ __forceinline__ int intersect_slab(const HotSlab& h, v3 o, v3 d, float& t_out, bool shadow_skip_planes) {
+__device__ __forceinline__ int intersect_slab(const HotSlab& h, v3 o, v3 d, float& t_out, bool shadow_skip_planes,
+                                              const float* occ = nullptr) {   // occ[i] = dot(c_i - o, c_i - o) if the caller has it
     MC_PT_DECISION_FP
     float t = h.inf;
     int id = -1;
@@ -298,7 +302,7 @@ __device__ __forceinline__ int intersect_slab(const HotSlab& h, v3 o, v3 d, floa
     for (int i = 0; i < 3; i++) {
         v3 oc = v3{h.c[i][0], h.c[i][1], h.c[i][2]} - o;                     // :317
         float b = dot(oc, d);                                                // :318
-        float det = (b * b - dot(oc, oc)) + h.r2[i];
+        float det = (b * b - (occ ? occ[i] : dot(oc, oc))) + h.r2[i];
         if (!(det < 0.0f)) {                                                 // :319
             float sq = dm::fsqrt<Fast>(det);
             float dd = b - sq;                                               // :322,324
@@ -319,14 +323,15 @@ __device__ __forceinline__ int intersect_slab(const HotSlab& h, v3 o, v3 d, floa
 // strictly below every root of the spheres before it and not above any root of the spheres after it.  dd_k is the value the
 // loop assigns for sphere k (:319-327), 1e20 when there is none.  Same comparisons on the same values: exact.
 template <bool Fast>
-__device__ __forceinline__ bool shadow_reaches_sphere(const HotSlab& h, v3 o, v3 d, int li) {
+__device__ __forceinline__ bool shadow_reaches_sphere(const HotSlab& h, v3 o, v3 d, int li, v3 oc_li, const float* occ) {
     MC_PT_DECISION_FP
     float dd[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        v3 oc = v3{h.c[i][0], h.c[i][1], h.c[i][2]} - o;                     // :317
+        // centre - o of the light (:408) and all three squared lengths were formed by the caller: the same operations
+        const v3 oc = i == li ? oc_li : v3{h.c[i][0], h.c[i][1], h.c[i][2]} - o;   // :317
         float b = dot(oc, d);                                                // :318
-        float det = (b * b - dot(oc, oc)) + h.r2[i];
+        float det = (b * b - occ[i]) + h.r2[i];
         float r = h.inf;
         if (!(det < 0.0f)) {                                                 // :319
             float sq = dm::fsqrt<Fast>(det);
@@ -338,7 +343,7 @@ __device__ __forceinline__ bool shadow_reaches_sphere(const HotSlab& h, v3 o, v3
         }
         dd[i] = r;
     }
-    // li is wave-uniform (the NEE loop index): scalar branches
+    // li is a constant of the caller's unrolled light loop
     if (li == 2) return dd[2] < dd[0] && dd[2] < dd[1] && dd[2] < h.inf;
     if (li == 1) return dd[1] < dd[0] && !(dd[2] < dd[1]) && dd[1] < h.inf;
     return !(dd[1] < dd[0]) && !(dd[2] < dd[0]) && dd[0] < h.inf;
@@ -464,17 +469,36 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
     v3 accrad{0.0f, 0.0f, 0.0f}, accmat{1.0f, 1.0f, 1.0f};               // :361
     v3 ro = a.lc, rd = normalize<Fast>(a.lc - spos);                      // :362
     float emissive = 1.0f;                                                // :365
+    // slab kernels: |c_i - ro|^2 of the three spheres travels with the ray origin.  Every material continues from the hit
+    // point x (:429,:434,:447), where the shadow rays of next-event estimation start too, so the value :318 needs at the next
+    // depth is the one formed at x in this one: once per bounce instead of twice (same operations, same operands).
+    float occ[3] = {0.0f, 0.0f, 0.0f};
+    if constexpr (Slab) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) { v3 oc = v3{hot.c[i][0], hot.c[i][1], hot.c[i][2]} - ro; occ[i] = dot(oc, oc); }
+    }
 
     MC_REGION(0);   // ray generation done
     for (uint32_t depth = 0; depth < a.max_depth; depth++) {              // :367
         MC_REGION(1);   // primary intersect
         float t;
         int id;
-        if constexpr (Slab) id = intersect_slab<Fast>(hot, ro, rd, t, false);
+        if constexpr (Slab) {
+            if (!sc.materials_known) {   // (uniform, cold) an unknown material kept its ray: occ must follow ro, not x
+#pragma unroll
+                for (int i = 0; i < 3; i++) { v3 oc = v3{hot.c[i][0], hot.c[i][1], hot.c[i][2]} - ro; occ[i] = dot(oc, oc); }
+            }
+        }
+        if constexpr (Slab) id = intersect_slab<Fast>(hot, ro, rd, t, false, occ);
         else id = intersect<Fast, NP, NS, Slab, Prec>(sc, uobj, ro, rd, t);
         if (id < 0) break;   // :369 `continue` with an unchanged ray misses again at every later depth: no effect
         MC_REGION(2);   // bounce prologue
         v3 x = ro + rd * t;                                               // :374 (o + t*d: fp32 mul is commutative)
+        v3 xoc[3];                                                        // c_i - x (:317 at the next depth, :408 now)
+        if constexpr (Slab) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) { xoc[i] = v3{hot.c[i][0], hot.c[i][1], hot.c[i][2]} - x; occ[i] = dot(xoc[i], xoc[i]); }
+        }
         const float* obj = lds_obj + 12 * id;                             // per-lane fetch from LDS
         const bool is_sphere = id >= np;
         v3 geo{obj[0], obj[1], obj[2]};
@@ -501,18 +525,23 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
         if (mat == 1) {                                                   // :400 diffuse
             MC_REGION(3);   // diffuse: NEE set-up + shadow ray
             const int n_lights = LdsScene ? (int)sc.n_emissive : ns;
-            for (int k = 0; k < n_lights; k++) {                          // :403
+#pragma unroll
+            for (int k = 0; k < (Slab ? 3 : n_lights); k++) {             // :403 (slab: unrolled, the index is a constant)
                 int i = k;
                 if (LdsScene) i = (int)lds_emissive[k];                   // host-built list of the spheres passing :407
                 else if (!((sc.emissive_mask >> i) & 1u)) continue;       // :407 (uniform)
                 const float* ls = uobj + 12 * (np + i);
-                const float lr2 = LdsScene ? ls[3] * ls[3] : sc.r2[i];
+                float lr2;
+                v3 lc;
+                if constexpr (Slab) { lr2 = hot.r2[i]; lc = v3{hot.c[i][0], hot.c[i][1], hot.c[i][2]}; }   // the VGPR copies
+                else { lr2 = LdsScene ? ls[3] * ls[3] : sc.r2[i]; lc = v3{ls[0], ls[1], ls[2]}; }
                 v3 le{ls[4], ls[5], ls[6]};
-                v3 xc = v3{ls[0], ls[1], ls[2]} - x;                      // :408
-                v3 sw = normalize<Fast>(xc);                              // :409
+                v3 xc = Slab ? xoc[i] : lc - x;                           // :408
+                const float xcc = Slab ? occ[i] : dot(xc, xc);
+                v3 sw = xc * dm::inversesqrt<Fast>(xcc);                  // :409 normalize(xc)
                 v3 su = normalize<Fast>(cross((__builtin_fabsf(sw.x) > 0.1f ? v3{0, 1, 0} : v3{1, 0, 0}), sw));
                 v3 sv = cross(sw, su);
-                float cos_a_max = dm::fsqrt<Fast>(1.0f - dm::fdiv<Fast>(lr2, dot(xc, xc)));   // :410
+                float cos_a_max = dm::fsqrt<Fast>(1.0f - dm::fdiv<Fast>(lr2, xcc));   // :410
                 float cos_a = (1.0f - rnd.x) + rnd.x * cos_a_max;         // :411
                 float sin_a = dm::fsqrt<Fast>(1.0f - cos_a * cos_a);
                 float phi = (2.0f * kPi) * rnd.y;                         // :412
@@ -522,7 +551,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 float tne;
                 bool reached;                                             // :420 shadow ray: is the nearest hit sphere i?
                 if constexpr (Slab) {
-                    if (sc.nee_skip_planes != 0u) reached = shadow_reaches_sphere<Fast>(hot, x, l, i);
+                    if (sc.nee_skip_planes != 0u) reached = shadow_reaches_sphere<Fast>(hot, x, l, i, xc, occ);
                     else reached = intersect_slab<Fast>(hot, x, l, tne, false) == np + i;
                 } else {
                     reached = intersect<Fast, NP, NS, Slab, Prec>(sc, uobj, x, l, tne, false) == np + i;

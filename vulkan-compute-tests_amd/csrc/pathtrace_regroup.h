@@ -395,16 +395,21 @@ __global__ void __launch_bounds__(64 * NW, 6) pathtrace_regroup_kernel(PTArgs a)
         if (kind == RG_D) {
             MC_REGION(3);   // diffuse: NEE set-up + shadow ray + bounce direction
             const v3 x = P.X, nl = P.V;
+#pragma unroll
             for (int i = 0; i < NS; i++) {                                    // :403
                 if (!((sc.emissive_mask >> i) & 1u)) continue;                // :407 (uniform)
                 const float* ls = uobj + 12 * (NP + i);
                 const float lr2 = sc.r2[i];
                 v3 le{ls[4], ls[5], ls[6]};
                 v3 xc = v3{ls[0], ls[1], ls[2]} - x;                          // :408
-                v3 sw = normalize<Fast>(xc);                                  // :409
+                float occ_x[3];
+#pragma unroll
+                for (int q = 0; q < 3; q++) { v3 oq = v3{hot.c[q][0], hot.c[q][1], hot.c[q][2]} - x; occ_x[q] = dot(oq, oq); }
+                const float xcc = dot(xc, xc);
+                v3 sw = xc * dm::inversesqrt<Fast>(xcc);                      // :409 normalize(xc)
                 v3 su = normalize<Fast>(cross((__builtin_fabsf(sw.x) > 0.1f ? v3{0, 1, 0} : v3{1, 0, 0}), sw));
                 v3 sv = cross(sw, su);
-                float cos_a_max = dm::fsqrt<Fast>(1.0f - dm::fdiv<Fast>(lr2, dot(xc, xc)));   // :410
+                float cos_a_max = dm::fsqrt<Fast>(1.0f - dm::fdiv<Fast>(lr2, xcc));   // :410
                 float cos_a = (1.0f - P.rx) + P.rx * cos_a_max;               // :411
                 float sin_a = dm::fsqrt<Fast>(1.0f - cos_a * cos_a);
                 float phi = (2.0f * kPi) * P.ry;                              // :412
@@ -412,7 +417,7 @@ __global__ void __launch_bounds__(64 * NW, 6) pathtrace_regroup_kernel(PTArgs a)
                 dm::sincos_angle<Fast>(phi, P.ry, sphi, cphi);
                 v3 l = normalize<Fast>(((su * cphi) * sin_a + (sv * sphi) * sin_a) + sw * cos_a);   // :413
                 float tne;
-                const bool reached = sc.nee_skip_planes != 0u ? shadow_reaches_sphere<Fast>(hot, x, l, i)   // :420 shadow ray
+                const bool reached = sc.nee_skip_planes != 0u ? shadow_reaches_sphere<Fast>(hot, x, l, i, xc, occ_x)   // :420 shadow ray
                                                                : intersect_slab<Fast>(hot, x, l, tne, false) == NP + i;
                 if (reached) {
                     float omega = (2.0f * kPi) * (1.0f - cos_a_max);          // :421
