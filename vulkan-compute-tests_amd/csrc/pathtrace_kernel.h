@@ -97,6 +97,22 @@ template <bool Fast> __device__ __forceinline__ v3 normalize(v3 a) { return a * 
 template <bool Fast> __device__ __forceinline__ v3 divs(v3 a, float s) {
     return v3{dm::fdiv<Fast>(a.x, s), dm::fdiv<Fast>(a.y, s), dm::fdiv<Fast>(a.z, s)};
 }
+// First tangent of the orthonormal basis around w (:409, :427): normalize(cross(|w.x| > 0.1 ? (0,1,0) : (1,0,0), w)).
+// Strict: the literal expression (its products with the axis' zeros decide the sign of zero components).
+// Fast (toleranced): the cross product is (w.z, 0, -w.x) or (0, -w.z, w.y) — one select, one fused squared length, two
+// scalings and three selects instead of two selects, nine cross-product operations, a 3-term dot and three scalings;
+// the non-zero components are the values the literal form produces under contraction.
+template <bool Fast> __device__ __forceinline__ v3 tangent_u(v3 w) {
+    const bool sel = __builtin_fabsf(w.x) > 0.1f;
+    if constexpr (Fast) {
+        const float q = sel ? w.x : w.y;
+        const float inv = dm::inversesqrt<true>(__builtin_fmaf(q, q, w.z * w.z));
+        const float zi = w.z * inv, qi = q * inv;
+        return v3{sel ? zi : 0.0f, sel ? 0.0f : -zi, sel ? -qi : qi};
+    } else {
+        return normalize<false>(cross(sel ? v3{0, 1, 0} : v3{1, 0, 0}, w));
+    }
+}
 // reflect(I,N) = I - 2*dot(N,I)*N
 __device__ __forceinline__ v3 reflect(v3 I, v3 N) { return I - N * (2.0f * dot(N, I)); }
 __device__ __forceinline__ v3 select(bool c, v3 a, v3 b) { return v3{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
@@ -539,7 +555,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 v3 xc = Slab ? xoc[i] : lc - x;                           // :408
                 const float xcc = Slab ? occ[i] : dot(xc, xc);
                 v3 sw = xc * dm::inversesqrt<Fast>(xcc);                  // :409 normalize(xc)
-                v3 su = normalize<Fast>(cross((__builtin_fabsf(sw.x) > 0.1f ? v3{0, 1, 0} : v3{1, 0, 0}), sw));
+                v3 su = tangent_u<Fast>(sw);
                 v3 sv = cross(sw, su);
                 float cos_a_max = dm::fsqrt<Fast>(1.0f - dm::fdiv<Fast>(lr2, xcc));   // :410
                 float cos_a = (1.0f - rnd.x) + rnd.x * cos_a_max;         // :411
@@ -565,7 +581,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             MC_REGION(8);   // diffuse bounce direction
             float r1 = (2.0f * kPi) * rnd.x, r2 = rnd.y, r2s = dm::fsqrt<Fast>(r2);   // :426
             v3 w = nl;
-            v3 u = normalize<Fast>(cross((__builtin_fabsf(w.x) > 0.1f ? v3{0, 1, 0} : v3{1, 0, 0}), w));   // :427
+            v3 u = tangent_u<Fast>(w);                                    // :427
             v3 v = cross(w, u);
             float s1, c1;
             dm::sincos_angle<Fast>(r1, rnd.x, s1, c1);

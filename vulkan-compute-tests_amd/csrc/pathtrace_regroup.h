@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(64 * NW, 6) pathtrace_regroup_kernel(PTArgs a)
                 for (int q = 0; q < 3; q++) { v3 oq = v3{hot.c[q][0], hot.c[q][1], hot.c[q][2]} - x; occ_x[q] = dot(oq, oq); }
                 const float xcc = dot(xc, xc);
                 v3 sw = xc * dm::inversesqrt<Fast>(xcc);                      // :409 normalize(xc)
-                v3 su = normalize<Fast>(cross((__builtin_fabsf(sw.x) > 0.1f ? v3{0, 1, 0} : v3{1, 0, 0}), sw));
+                v3 su = tangent_u<Fast>(sw);
                 v3 sv = cross(sw, su);
                 float cos_a_max = dm::fsqrt<Fast>(1.0f - dm::fdiv<Fast>(lr2, xcc));   // :410
                 float cos_a = (1.0f - P.rx) + P.rx * cos_a_max;               // :411
@@ -426,7 +426,7 @@ __global__ void __launch_bounds__(64 * NW, 6) pathtrace_regroup_kernel(PTArgs a)
             }
             float r1 = (2.0f * kPi) * P.rx, r2 = P.ry, r2s = dm::fsqrt<Fast>(r2);   // :426
             v3 w = nl;
-            v3 u = normalize<Fast>(cross((__builtin_fabsf(w.x) > 0.1f ? v3{0, 1, 0} : v3{1, 0, 0}), w));   // :427
+            v3 u = tangent_u<Fast>(w);   // :427
             v3 vv = cross(w, u);
             float s1, c1;
             dm::sincos_angle<Fast>(r1, P.rx, s1, c1);
