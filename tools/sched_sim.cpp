@@ -253,6 +253,69 @@ void sim_twoslot(const Tile& t, int pix0, int spp, int max_depth, const Cost& c,
     st.cost += c.commit_item * total_items;
 }
 
+
+// ---------------------------------------------------------------- lane-private sample streams (path regeneration)
+// A wave owns 64/S pixels for the whole sample range.  Lane (pixel, j) traces the samples j, j + S, j + 2S, ... of its pixel one
+// after the other and starts the next one the moment a path ends — no round barrier.  Camera rays come from a per-lane stash
+// that is topped up to `stash` rays for all lanes at once (wave-uniform point, full width) whenever some lane runs dry.
+// S = 1: the lane IS the pixel and adds its samples in order by itself (bit-exact, no exchange).  S > 1: results go through a
+// ring of `lookahead` rounds in LDS; a round is committed (ordered fold) when all 64 lanes have finished it, and a lane
+// may run at most `lookahead` rounds ahead of the last committed one.
+struct StreamCfg { int S = 1; int lookahead = 1 << 30; int stash = 4; double fin = 20, ov = 6, fold = 96; };
+void sim_streams(const Tile& t, int pix0, int spp, int max_depth, const Cost& c, const StreamCfg& g, Stats& st) {
+    const int S = g.S, per_lane = (spp + S - 1) / S;
+    int k[64], pos[64], stash[64], active[64];   // k: index of the sample in flight (or next); active: a path is in flight
+    for (int l = 0; l < 64; l++) { k[l] = 0; pos[l] = 0; stash[l] = 0; active[l] = 0; }
+    auto sample_of = [&](int l, int kk) { return kk * S + l % S; };
+    auto path = [&](int l, int kk) -> const std::vector<uint8_t>& { return t.samples[(size_t)(pix0 + l / S) * spp + sample_of(l, kk)]; };
+    auto exists = [&](int l, int kk) { return kk < per_lane && sample_of(l, kk) < spp; };
+    int committed = 0;   // rounds folded so far (S > 1)
+    for (;;) {
+        // lanes without a path start their next sample if the window allows it; an empty stash triggers a wave-wide refill
+        bool need_refill = false;
+        for (int l = 0; l < 64; l++)
+            if (!active[l] && exists(l, k[l]) && k[l] < committed + g.lookahead && stash[l] == 0) need_refill = true;
+        if (need_refill) {
+            int most = 0; double sum = 0;
+            for (int l = 0; l < 64; l++) {
+                int remaining = 0;
+                for (int kk = k[l] + (active[l] ? 1 : 0); kk < per_lane && exists(l, kk); kk++) remaining++;
+                int want = std::min(g.stash, remaining) - stash[l];
+                if (want < 0) want = 0;
+                stash[l] += want; most = std::max(most, want); sum += want;
+            }
+            st.cost += most * c.cam; st.useful += sum * c.cam / 64.0;
+        }
+        int nstart = 0;
+        for (int l = 0; l < 64; l++)
+            if (!active[l] && exists(l, k[l]) && k[l] < committed + g.lookahead && stash[l] > 0) { stash[l]--; active[l] = 1; pos[l] = 0; nstart++; }
+        int na = 0, nd = 0, ng = 0, nm = 0, nfin = 0;
+        for (int l = 0; l < 64; l++) {
+            if (!active[l]) continue;
+            na++;
+            const auto& ev = path(l, k[l]);
+            bool fin = false;
+            if (pos[l] >= (int)ev.size()) fin = true;                       // miss: intersect ran, nothing else
+            else { int e = ev[pos[l]++]; if (e == 0) fin = true; else { if (e == 1) nd++; else if (e == 2) nm++; else ng++; if (pos[l] >= max_depth) fin = true; } }
+            if (fin) { active[l] = 0; k[l]++; nfin++; st.n_samples++; }
+        }
+        if (!na) {
+            bool any_left = false;
+            for (int l = 0; l < 64; l++) if (exists(l, k[l])) any_left = true;
+            if (!any_left) break;
+            // every lane waits for the window: cannot happen (the slowest lane is always inside it)
+        }
+        st.iters += na ? 1 : 0;
+        st.cost += (na ? c.ip : 0) + (nd ? c.d : 0) + (ng ? c.g : 0) + (nm ? c.m : 0) + g.ov + ((nfin || nstart) ? g.fin : 0);
+        st.useful += (na * c.ip + nd * c.d + ng * c.g + nm * c.m + (nfin + nstart) * g.fin / 2) / 64.0;
+        if (S > 1) {
+            int mn = 1 << 30;
+            for (int l = 0; l < 64; l++) mn = std::min(mn, exists(l, k[l]) || active[l] ? k[l] : per_lane);
+            while (committed < mn) { committed++; st.cost += g.fold; st.useful += g.fold; }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- rounds kernel with samples SORTED by path length
 // Within a window of `window` consecutive samples of each pixel the samples are traced in order of (predicted) path length,
 // 16 per pixel and round, so that a round's lanes finish together; the ordered fold then needs the window's results in
@@ -319,12 +382,14 @@ void sim_sorted_rounds(const Tile& t, int pixels, int spp, int max_depth, const 
 }  // namespace
 
 int main(int argc, char** argv) {
-    int W = 900, H = 600, spp = 500, max_depth = 12, n_tiles = 32, pixels = 32;
+    int W = 900, H = 600, spp = 500, max_depth = 12, n_tiles = 32, pixels = 64;
+    bool only_streams = false;
     unsigned seed = 1;
     for (int i = 1; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--spp")) spp = atoi(argv[i + 1]);
         if (!strcmp(argv[i], "--tiles")) n_tiles = atoi(argv[i + 1]);
         if (!strcmp(argv[i], "--seed")) seed = atoi(argv[i + 1]);
+        if (!strcmp(argv[i], "--only")) only_streams = !strcmp(argv[i + 1], "streams");
     }
     oracle::PT<TracePolicy> pt;
     pt.planes = kPlanes; pt.nPlanes = 6; pt.spheres = kSpheres; pt.nSpheres = 3; pt.mathMode = oracle::MATH_LIBM;
@@ -332,15 +397,19 @@ int main(int argc, char** argv) {
     std::vector<Tile> tiles(n_tiles);
     double bounces = 0, nsamp = 0, hist[4] = {0, 0, 0, 0};
     for (auto& t : tiles) {
-        int x0 = (rng() % (W / 8)) * 8, y0 = (rng() % (H / 4)) * 4;
+        int x0 = (rng() % (W / 8)) * 8, y0 = (rng() % (H / 8)) * 8;
         t.samples.resize((size_t)pixels * spp);
         t.gx.resize(pixels); t.gy.resize(pixels);
-        for (int p = 0; p < pixels; p++) { t.gx[p] = x0 + (p % 16) % 4 + 4 * (p / 16); t.gy[p] = y0 + (p % 16) / 4; }
+        // 64 pixels = an 8 x 8 square made of four 4 x 4 blocks (pixels 0..15, 16..31, ...): a wave of the S = 1 stream kernel,
+        // or 4 blocks of the S = 16 kernels
+        auto px = [&](int p) { return x0 + (p % 16) % 4 + 4 * ((p / 16) % 2); };
+        auto py = [&](int p) { return y0 + (p % 16) / 4 + 4 * (p / 32); };
+        for (int p = 0; p < pixels; p++) { t.gx[p] = px(p); t.gy[p] = py(p); }
         for (int p = 0; p < pixels; p++)
             for (int s = 0; s < spp; s++) {
                 auto& ev = t.samples[(size_t)p * spp + s];
                 g_events = &ev;
-                pt.sample(x0 + (p % 16) % 4 + 4 * (p / 16), y0 + (p % 16) / 4, W, H, s, max_depth);
+                pt.sample(px(p), py(p), W, H, s, max_depth);
                 bounces += ev.size(); nsamp++;
                 for (auto e : ev) hist[e]++;
             }
@@ -352,6 +421,17 @@ int main(int argc, char** argv) {
     for (auto& t : tiles) sim_rounds(t, pixels, spp, max_depth, c, base);
     printf("%-58s cost/sample %7.1f  lanes %.3f  iters/64samples %.2f\n", "rounds (round 1 kernel)", base.cost / base.n_samples,
            base.useful / base.cost, base.iters * 64.0 / base.n_samples);
+    for (int S : {1, 4, 16})
+        for (int la : {1, 2, 3, 4, 6, 8, 1 << 30})
+            for (int stash : {2, 4}) {
+                if (S == 1 && la != (1 << 30)) continue;
+                StreamCfg g; g.S = S; g.lookahead = la; g.stash = stash; g.fold = S == 1 ? 0 : 96.0 * S / 16;
+                Stats s;
+                for (auto& t : tiles) for (int p0 = 0; p0 + 64 / S <= pixels; p0 += 64 / S) sim_streams(t, p0, spp, max_depth, c, g, s);
+                printf("streams S=%2d lookahead=%10d stash=%d : cost/sample %7.1f (%.3fx)  lanes %.3f  iters/64samples %.2f\n", S, la, stash,
+                       s.cost / s.n_samples, (base.cost / base.n_samples) / (s.cost / s.n_samples), s.useful / s.cost, s.iters * 64.0 / s.n_samples);
+            }
+    if (only_streams) return 0;
     struct Named { const char* name; RegroupCfg cfg; };
     std::vector<Named> cfgs;
     for (int waves : {1, 4, 8})
