@@ -311,7 +311,8 @@ struct HotSlab {
 // (W - o[a]) / d[a] with W = pos ? w_pos : -w_neg: one select and one subtraction instead of two additions and a select.
 template <bool Fast>
 __device__ __forceinline__ int intersect_slab(const HotSlab& h, v3 o, v3 d, float& t_out, bool shadow_skip_planes,
-                                              const float* occ = nullptr) {   // occ[i] = dot(c_i - o, c_i - o) if the caller has it
+                                              const float* occ = nullptr,     // occ[i] = dot(c_i - o, c_i - o) and
+                                              const v3* oc_at_o = nullptr) {  // oc_at_o[i] = c_i - o if the caller has them
     MC_PT_DECISION_FP
     float t = h.inf;
     int id = -1;
@@ -327,7 +328,7 @@ __device__ __forceinline__ int intersect_slab(const HotSlab& h, v3 o, v3 d, floa
     }
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        v3 oc = v3{h.c[i][0], h.c[i][1], h.c[i][2]} - o;                     // :317
+        v3 oc = oc_at_o ? oc_at_o[i] : v3{h.c[i][0], h.c[i][1], h.c[i][2]} - o;   // :317
         float b = dot(oc, d);                                                // :318
         float det = (b * b - (occ ? occ[i] : dot(oc, oc))) + h.r2[i];
         if (!(det < 0.0f)) {                                                 // :319
@@ -499,25 +500,24 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
     // slab kernels: |c_i - ro|^2 of the three spheres travels with the ray origin.  Every material continues from the hit
     // point x (:429,:434,:447), where the shadow rays of next-event estimation start too, so the value :318 needs at the next
     // depth is the one formed at x in this one: once per bounce instead of twice (same operations, same operands).
+    // The slab kernels' loop is rotated: the intersection of depth k + 1 is computed at the end of depth k, where c_i - x is still
+    // in registers, so those nine subtractions are made once per bounce too.
     float occ[3] = {0.0f, 0.0f, 0.0f};
-    if constexpr (Slab) {
-#pragma unroll
-        for (int i = 0; i < 3; i++) { v3 oc = v3{hot.c[i][0], hot.c[i][1], hot.c[i][2]} - ro; occ[i] = dot(oc, oc); }
-    }
-
+    float t = 0.0f;
+    int id = -1;
     MC_REGION(0);   // ray generation done
-    for (uint32_t depth = 0; depth < a.max_depth; depth++) {              // :367
-        MC_REGION(1);   // primary intersect
-        float t;
-        int id;
-        if constexpr (Slab) {
-            if (!sc.materials_known) {   // (uniform, cold) an unknown material kept its ray: occ must follow ro, not x
+    if constexpr (Slab) {
+        MC_REGION(1);   // primary intersect (camera ray)
+        v3 oc0[3];
 #pragma unroll
-                for (int i = 0; i < 3; i++) { v3 oc = v3{hot.c[i][0], hot.c[i][1], hot.c[i][2]} - ro; occ[i] = dot(oc, oc); }
-            }
+        for (int i = 0; i < 3; i++) { oc0[i] = v3{hot.c[i][0], hot.c[i][1], hot.c[i][2]} - ro; occ[i] = dot(oc0[i], oc0[i]); }
+        if (a.max_depth != 0u) id = intersect_slab<Fast>(hot, ro, rd, t, false, occ, oc0);
+    }
+    for (uint32_t depth = 0; depth < a.max_depth; depth++) {              // :367
+        if constexpr (!Slab) {
+            MC_REGION(1);   // primary intersect
+            id = intersect<Fast, NP, NS, Slab, Prec>(sc, uobj, ro, rd, t);
         }
-        if constexpr (Slab) id = intersect_slab<Fast>(hot, ro, rd, t, false, occ);
-        else id = intersect<Fast, NP, NS, Slab, Prec>(sc, uobj, ro, rd, t);
         if (id < 0) break;   // :369 `continue` with an unchanged ray misses again at every later depth: no effect
         MC_REGION(2);   // bounce prologue
         v3 x = ro + rd * t;                                               // :374 (o + t*d: fp32 mul is commutative)
@@ -634,6 +634,16 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             }
             ro = x;
             emissive = 1.0f;                                              // :447
+        }
+        if constexpr (Slab) {
+            if (depth + 1u < a.max_depth) {                               // (uniform) the intersection of the next depth
+                MC_REGION(1);
+                if (!sc.materials_known) {   // (uniform, cold) an unknown material kept its ray: c_i - o must follow ro, not x
+#pragma unroll
+                    for (int i = 0; i < 3; i++) { xoc[i] = v3{hot.c[i][0], hot.c[i][1], hot.c[i][2]} - ro; occ[i] = dot(xoc[i], xoc[i]); }
+                }
+                id = intersect_slab<Fast>(hot, ro, rd, t, false, occ, xoc);
+            }
         }
     }
     return accrad;
