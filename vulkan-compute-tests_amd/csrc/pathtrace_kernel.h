@@ -567,10 +567,12 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 v3 le{ls[4], ls[5], ls[6]};
                 v3 xc = Slab ? xoc[i] : lc - x;                           // :408
                 const float xcc = Slab ? occ[i] : dot(xc, xc);
-                v3 sw = xc * dm::inversesqrt<Fast>(xcc);                  // :409 normalize(xc)
+                const float inv_len = dm::inversesqrt<Fast>(xcc);
+                v3 sw = xc * inv_len;                                     // :409 normalize(xc)
                 v3 su = tangent_u<Fast>(sw);
                 v3 sv = cross(sw, su);
-                float cos_a_max = dm::fsqrt<Fast>(1.0f - dm::fdiv<Fast>(lr2, xcc));   // :410
+                // :410; fast: 1 / |xc|^2 is the square of the 1 / |xc| above (one multiply instead of a v_rcp_f32)
+                float cos_a_max = dm::fsqrt<Fast>(1.0f - (Fast ? lr2 * (inv_len * inv_len) : dm::fdiv<Fast>(lr2, xcc)));
                 float cos_a = (1.0f - rnd.x) + rnd.x * cos_a_max;         // :411
                 float sin_a = dm::fsqrt<Fast>(1.0f - cos_a * cos_a);
                 float phi = (2.0f * kPi) * rnd.y;                         // :412
