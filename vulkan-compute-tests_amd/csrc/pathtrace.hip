@@ -132,6 +132,7 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
     a.max_depth = p->max_depth; a.row_begin = p->row_begin; a.row_end = p->row_end;
     a.row_block = p->row_stride ? p->row_block : 0u; a.row_stride = p->row_stride;
     set_camera(a);
+    a.inv_W = 1.0f / (float)p->width; a.inv_H = 1.0f / (float)p->height; a.inv_spp = 1.0f / (float)p->spp;
     a.out = (float4*)d_rgba;
     a.scene.n_planes = n_planes; a.scene.n_spheres = n_spheres;
     const int prec = (int)((p->flags >> 16) & 0xfu);   // MC_PT_PRECISION(x)
@@ -151,6 +152,12 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
             if (h_dot(e, e) > 0.0f) a.scene.emissive_mask |= 1u << i;
         }
         a.scene.nee_skip_planes = lights_inside_box(a.scene, spheres, n_spheres, a.cam_o, a.lc) ? 1u : 0u;
+        for (uint32_t i = 0; i < 3; i++) {   // c_i - lc and its squared length, as dot() associates: (x*x + y*y) + z*z
+            const float* sp = spheres + 12 * i;
+            const float ox = sp[0] - a.lc.x, oy = sp[1] - a.lc.y, oz = sp[2] - a.lc.z;
+            a.cam_oc[i][0] = ox; a.cam_oc[i][1] = oy; a.cam_oc[i][2] = oz;
+            a.cam_occ[i] = (ox * ox + oy * oy) + oz * oz;
+        }
         a.scene.materials_known = 1u;
         for (uint32_t i = 0; i < n_planes + n_spheres; i++) {
             const float m = floorf(a.scene.obj[12 * i + 11] + 0.5f);          // the kernel's int(floor(m + 0.5)), :378/:384

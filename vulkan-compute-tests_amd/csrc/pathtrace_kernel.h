@@ -78,6 +78,12 @@ struct PTArgs {
     uint32_t W, H, spp, sample_begin, sample_end, max_depth, row_begin, row_end, row_block, row_stride;
     // camera basis (pathTracer.comp:352-353,360), evaluated once on the host with the same IEEE ops
     v3 cam_o, cam_d, cx, cy, lc;
+    // slab kernels: sphere centre - lc and its squared length for the camera ray's intersect (:317-:318 with o = lc), the same
+    // IEEE operations evaluated once on the host — wave-uniform values that would otherwise sit in (spilled) vector registers
+    float cam_oc[3][3], cam_occ[3];
+    // fast mode: 1/W, 1/H, 1/spp (host: 1.0f / x) for the sensor position (:358-:359) and accrad / samps.y (:452) — uniform
+    // reciprocals the kernel would otherwise form with v_rcp_f32 and carry in vector registers through every round
+    float inv_W, inv_H, inv_spp;
     float4* __restrict__ out;   // tile-local storage rows
     uint32_t* status;           // context-owned device word: a kernel ORs a bit in when a scheduler bound trips (else untouched)
     SceneArgs scene;
@@ -491,8 +497,9 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
     float tentx = rnd2x < 1.0f ? dm::fsqrt<Fast>(rnd2x) - 1.0f : 1.0f - dm::fsqrt<Fast>(2.0f - rnd2x);
     float tenty = rnd2y < 1.0f ? dm::fsqrt<Fast>(rnd2y) - 1.0f : 1.0f - dm::fsqrt<Fast>(2.0f - rnd2y);
     float stratx = (float)((samp / 2u) % 2u), straty = (float)(samp % 2u);
-    float sx = (dm::fdiv<Fast>((float)gx + 0.5f * ((0.5f + stratx) + tentx), (float)a.W) - 0.5f) * 0.036f;
-    float sy = (dm::fdiv<Fast>((float)gy + 0.5f * ((0.5f + straty) + tenty), (float)a.H) - 0.5f) * 0.024f;
+    const float px = (float)gx + 0.5f * ((0.5f + stratx) + tentx), py = (float)gy + 0.5f * ((0.5f + straty) + tenty);
+    float sx = ((Fast ? px * a.inv_W : dm::fdiv<Fast>(px, (float)a.W)) - 0.5f) * 0.036f;
+    float sy = ((Fast ? py * a.inv_H : dm::fdiv<Fast>(py, (float)a.H)) - 0.5f) * 0.024f;
     v3 spos = (a.cam_o + a.cx * sx) + a.cy * sy;                          // :360
     v3 accrad{0.0f, 0.0f, 0.0f}, accmat{1.0f, 1.0f, 1.0f};               // :361
     v3 ro = a.lc, rd = normalize<Fast>(a.lc - spos);                      // :362
@@ -510,7 +517,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
         MC_REGION(1);   // primary intersect (camera ray)
         v3 oc0[3];
 #pragma unroll
-        for (int i = 0; i < 3; i++) { oc0[i] = v3{hot.c[i][0], hot.c[i][1], hot.c[i][2]} - ro; occ[i] = dot(oc0[i], oc0[i]); }
+        for (int i = 0; i < 3; i++) { oc0[i] = v3{a.cam_oc[i][0], a.cam_oc[i][1], a.cam_oc[i][2]}; occ[i] = a.cam_occ[i]; }
         if (a.max_depth != 0u) id = intersect_slab<Fast>(hot, ro, rd, t, false, occ, oc0);
     }
     for (uint32_t depth = 0; depth < a.max_depth; depth++) {              // :367
@@ -676,27 +683,43 @@ __global__ void __launch_bounds__(256, Fast ? 6 : 5) pathtrace_kernel(PTArgs a) 
         stage_records(lds_obj, a.scene.obj, a.scene.n_planes + a.scene.n_spheres, Slab);
     }
     constexpr uint32_t TW = WaveTile<S>::w, TH = WaveTile<S>::h;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t j = lane % (uint32_t)S;          // sample slot of this lane within its pixel
-    const uint32_t pix = lane / (uint32_t)S;        // pixel of this lane within the wave tile
-    const uint32_t gx = blockIdx.x * (2u * TW) + (wave & 1u) * TW + (pix % TW);
-    const uint32_t ty = blockIdx.y * (2u * TH) + (wave >> 1) * TH + (pix / TW);   // tile-local storage row
-    const uint32_t r = tile_row_to_storage(ty, a.row_begin, a.row_block, a.row_stride);
-    const bool valid = gx < a.W && r < a.row_end;                               // pathTracer.comp:348
-    const uint32_t gy = a.H - 1u - (valid ? r : 0u);                            // :349 gid = (H-1-y)*W + x
-    const size_t idx = valid ? (size_t)ty * a.W + gx : 0;
+    // Pixel / sample slot of a lane.  Derived afresh from the thread id wherever it is needed — before the loop (accumulator
+    // load), at the head of every round, after the loop (store) — through an opaque copy the compiler cannot merge with the
+    // previous one: the ten-odd derived values are then dead inside the bounce loop instead of being carried through it
+    // (the 80-VGPR budget of 6 waves per SIMD spilled them to scratch: 0.7 GB of HBM writes per launch, r02 profile).
+    struct LaneCoords { uint32_t j, group_base, gx, gy; size_t idx; bool valid; };
+    auto lane_coords = [&]() {
+        uint32_t tid = threadIdx.x, row_block = a.row_block;
+        asm volatile("" : "+v"(tid));
+        asm volatile("" : "+s"(row_block));          // (the division's reciprocal of this uniform is not worth a register either)
+        const uint32_t lane = tid & 63u, wave = tid >> 6;
+        LaneCoords c;
+        c.j = lane % (uint32_t)S;                    // sample slot of this lane within its pixel
+        const uint32_t pix = lane / (uint32_t)S;     // pixel of this lane within the wave tile
+        c.group_base = lane - c.j;                   // first lane of this pixel's group
+        c.gx = blockIdx.x * (2u * TW) + (wave & 1u) * TW + (pix % TW);
+        const uint32_t ty = blockIdx.y * (2u * TH) + (wave >> 1) * TH + (pix / TW);   // tile-local storage row
+        const uint32_t r = tile_row_to_storage(ty, a.row_begin, row_block, a.row_stride);
+        c.valid = c.gx < a.W && r < a.row_end;                                  // pathTracer.comp:348
+        c.gy = a.H - 1u - (c.valid ? r : 0u);                                   // :349 gid = (H-1-y)*W + x
+        c.idx = c.valid ? (size_t)ty * a.W + c.gx : 0;
+        return c;
+    };
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (valid && a.sample_begin > 0) acc = a.out[idx];   // progressive continuation (samps.x protocol); s==0 resets (:451)
+    if (a.sample_begin > 0) {   // progressive continuation (samps.x protocol); s==0 resets (:451)
+        const LaneCoords c = lane_coords();
+        if (c.valid) acc = a.out[c.idx];
+    }
     const float fspp = (float)a.spp;
     HotSlab hot;
     if constexpr (Slab) hot.load(a.scene);
-    const uint32_t group_base = lane - j;           // first lane of this pixel's group
     for (uint32_t base = a.sample_begin; base < a.sample_end; base += (uint32_t)S) {
-        const uint32_t s = base + j;
+        const LaneCoords c = lane_coords();
+        const uint32_t s = base + c.j;
         v3 q{0.0f, 0.0f, 0.0f};
-        if (valid && s < a.sample_end) {
-            v3 rad = trace_sample<Fast, NP, NS, Slab, Prec>(a, lds_obj, lds_emissive, hot, gx, gy, s);
-            q = divs<Fast>(rad, fspp);                                          // :452 accrad / samps.y
+        if (c.valid && s < a.sample_end) {
+            v3 rad = trace_sample<Fast, NP, NS, Slab, Prec>(a, lds_obj, lds_emissive, hot, c.gx, c.gy, s);
+            q = Fast ? rad * a.inv_spp : divs<Fast>(rad, fspp);                 // :452 accrad / samps.y
         }
         // fold the round's S samples into the accumulator in sample order (every lane of the group
         // performs the same additions, so all S copies of acc stay identical)
@@ -704,12 +727,22 @@ __global__ void __launch_bounds__(256, Fast ? 6 : 5) pathtrace_kernel(PTArgs a) 
         if (S == 1) {
             acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += 0.0f;
         } else {
+            uint32_t tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const uint32_t first = (tid & 63u) - (tid & 63u) % (uint32_t)S;     // = group_base, derived after the bounce loop
+            auto from_lane = [](float v, uint32_t src) {                        // __shfl without its own lane-id bookkeeping
+                return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src << 2), __float_as_int(v)));
+            };
             for (uint32_t k = 0; k < count; k++) {
-                const int src = (int)(group_base + k);
-                acc.x += __shfl(q.x, src); acc.y += __shfl(q.y, src); acc.z += __shfl(q.z, src); acc.w += 0.0f;
+                const uint32_t src = first + k;
+                acc.x += from_lane(q.x, src); acc.y += from_lane(q.y, src); acc.z += from_lane(q.z, src); acc.w += 0.0f;
             }
         }
     }
+    const LaneCoords c = lane_coords();
+    const bool valid = c.valid;
+    const uint32_t j = c.j;
+    const size_t idx = c.idx;
     if (a.sample_end == a.spp) {                                                // :453 after sample spp-1
         acc.x = dm::fpow<Fast>(dm::gmin(dm::gmax(acc.x, 0.0f), 1.0f), 0.45f) * 255.0f + 0.5f;
         acc.y = dm::fpow<Fast>(dm::gmin(dm::gmax(acc.y, 0.0f), 1.0f), 0.45f) * 255.0f + 0.5f;
