@@ -334,8 +334,9 @@ def main():
                                       "note": ("142 = the reference composition's literal flop count; the kernel gets the same "
                                                "bits from ~87 issued instructions (Dekker error term = one fma, exact), "
                                                "so this fraction may exceed 1") if (not is_pt and cfg["ds"]) else
-                                              ("fast math: hardware transcendentals and a*b+c contraction (toleranced parity); "
-                                               "the strict kernel, reported beside it, forbids both") if is_pt and args.math == "fast"
+                                              ("fast math: hardware transcendentals, a*b+c contraction, identities of exact arithmetic not executed "
+                                               "(toleranced parity; the algorithmic flop count is the reference's, not the executed one); "
+                                               "the strict kernel, reported beside it, forbids all three") if is_pt and args.math == "fast"
                                               else "parity forbids contraction: one issue slot per flop"}},
         }
 
