@@ -83,6 +83,14 @@ def fuzz_pathtrace(rng, ctx, B, O):
         if rng.random() < 0.6:   # pull most lights inside the room so that the shadow-ray shortcut is exercised
             spheres[i, 3] = np.float32(rng.uniform(0.05, 0.4))
             spheres[i, 0:3] = rng.uniform(lo + 1.2, hi - 1.2).astype(np.float32)
+    if rng.random() < 0.08:   # a material code outside 1..3 leaves the ray where it was (no branch of :400-448 matches)
+        code = float(rng.choice([0.0, 4.0, 0.4, 3.5, -1.0, 7.0]))
+        if rng.random() < 0.5:
+            planes[rng.integers(6), 11] = code
+        else:
+            spheres[rng.integers(3), 11] = code
+    if rng.random() < 0.05:   # extreme radii: roots far outside / tiny discriminants
+        spheres[rng.integers(3), 3] = np.float32(rng.choice([1e-3, 1e-2, 5.0, 30.0]))
     W, H, spp = int(rng.integers(1, 40)), int(rng.integers(1, 28)), int(rng.integers(1, 20))
     depth = int(rng.choice([12, 12, 12, 3, 7, 15]))
     flags = int(rng.choice([0, B.pt_force_s(1), B.pt_force_s(4), B.pt_force_s(16), B.PT_GENERIC_KERNEL]))
