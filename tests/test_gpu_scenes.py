@@ -150,3 +150,25 @@ def test_unknown_material_codes_keep_their_ray(ctx, B, O, which, code):
     for flags in (0, B.pt_force_s(1), B.pt_force_s(16), B.PT_GENERIC_KERNEL):
         out = ctx.pathtrace(B.pathtrace_params(W, H, spp, flags=flags), planes=planes, spheres=spheres)
         assert np.array_equal(bits(out), bits(ref)), (which, code, flags)
+
+
+def test_fast_mode_on_a_scene_with_non_unit_plane_normals(ctx, B, O):
+    """The reference uses a plane's normal as given (pathTracer.comp:387): scaling (n, w) of a wall describes the same plane but
+    a longer shading normal, and the normalize of :428 / :441 then really rescales.  The fast mode's "unit combination" shortcut
+    is for the slab kernels only (axis normals of length exactly 1); this scene takes the generic kernel and must stay within
+    the small-size fast tolerance of the oracle — a kernel that skipped the normalize there would be off by tens of units."""
+    planes, spheres = _box_scene(O)
+    planes[1, 0:4] *= 1.5          # right wall: normal (1.5, 0, 0), w scaled alike
+    planes[2, 0:4] *= 0.75         # ceiling
+    planes[4, 11] = 3.0            # the back wall refracts (tdir of :441 from a plane normal)
+    assert B.pathtrace_scene_class(planes, spheres) == 0
+    W, H, spp = 96, 64, 64
+    ref = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_LIBM)[..., :3].astype(np.float64)
+    strict = ctx.pathtrace(B.pathtrace_params(W, H, spp), planes=planes, spheres=spheres)
+    assert np.array_equal(bits(strict), bits(O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC)))
+    for flags in (0, B.pt_force_s(1), B.pt_force_s(16)):
+        fast = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, flags=flags), planes=planes, spheres=spheres)
+        d = fast[..., :3].astype(np.float64) - ref
+        rmse, p999 = np.sqrt((d ** 2).mean()), np.percentile(np.sqrt((d ** 2).sum(-1)), 99.9)
+        print(f"non-unit normals, fast generic flags={flags}: rmse {rmse:.4f} p99.9 {p999:.3f}")
+        assert rmse <= 0.75 and p999 <= 5.0 and abs(d.mean()) < 0.25

@@ -103,8 +103,10 @@ __device__ __forceinline__ void mc_sincos(float x, float& s, float& c) {
     float sk = sin_kernel(r), ck = cos_kernel(r);
     float sv = (k & 1) ? ck : sk;
     float cv = (k & 1) ? sk : ck;
-    s = (k & 2) ? -sv : sv;
-    c = ((k + 1) & 2) ? -cv : cv;
+    // conditional negation = flipping the sign bit (also of a zero or a NaN, as the unary minus does): bit 1 of k, moved to
+    // bit 31, xor-ed in — three 2-cycle integer operations instead of a compare and a select of the 4-cycle class
+    s = as_float(as_uint(sv) ^ (((uint32_t)k << 30) & 0x80000000u));
+    c = as_float(as_uint(cv) ^ (((uint32_t)(k + 1) << 30) & 0x80000000u));
 }
 
 // sin/cos of angle = two_pi_f32 * u where `angle` is the already-rounded fp32 product the shader

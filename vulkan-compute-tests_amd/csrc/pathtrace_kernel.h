@@ -122,13 +122,9 @@ template <bool Fast> __device__ __forceinline__ v3 tangent_u(v3 w) {
 // normalize() of a combination a*u + b*v + c*w of an orthonormal basis with a^2 + b^2 + c^2 = 1 (the sampled directions of
 // :413 and :428).  Strict: the literal normalize.  Fast (toleranced): the vector is already of unit length to within the
 // accuracy of v_sin/v_cos/v_sqrt (~1e-6), which is what the rescaling would remove; it is used as it is.
-template <bool Fast> __device__ __forceinline__ v3 normalize_unit_combination(v3 a) {
-#ifdef MC_PT_FAST_KEEP_UNIT_NORMALIZE
-    return normalize<Fast>(a);
-#else
-    if constexpr (Fast) return a;
-    else return normalize<false>(a);
-#endif
+template <bool Fast, bool UnitBasis> __device__ __forceinline__ v3 normalize_unit_combination(v3 a) {
+    if constexpr (Fast && UnitBasis) return a;
+    else return normalize<Fast>(a);
 }
 // reflect(I,N) = I - 2*dot(N,I)*N
 __device__ __forceinline__ v3 reflect(v3 I, v3 N) { return I - N * (2.0f * dot(N, I)); }
@@ -544,7 +540,14 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
         // (fast mode keeps this normalize: a grazing hit's t = b - sqrt(det) cancels, x leaves the sphere by far more than an
         // ulp and (x - c) / r is visibly wrong: rmse 0.40 / p99.9 7.4 against the 0.5 / 4 bound, measured)
         v3 n = is_sphere ? normalize<Fast>(x - geo) : geo;                // :381/:387
-        v3 nl = dot(n, rd) < 0.0f ? n : -n;                               // :390
+        v3 nl;                                                            // :390 nl = dot(n, rd) < 0 ? n : -n
+        if constexpr (Fast) {   // the sign bit of the dot product, inverted, flips n: 5 two-cycle integer operations instead of a
+                                // compare and three selects (differs from `<` only for a dot product of exactly -0)
+            const uint32_t flip = ~dm::as_uint(dot(n, rd)) & 0x80000000u;
+            nl = v3{dm::as_float(dm::as_uint(n.x) ^ flip), dm::as_float(dm::as_uint(n.y) ^ flip), dm::as_float(dm::as_uint(n.z) ^ flip)};
+        } else {
+            nl = dot(n, rd) < 0.0f ? n : -n;
+        }
         // :391 accrad += accmat * e * emissive.  For an object without emission (e = +-0) the product is a zero and
         // accrad (never -0: it starts at +0 and only receives sums) is unchanged, so the nine operations are skipped when no
         // lane of the wave hit an emitter — almost always (slab kernels; the flag sits in the record's unused slot 3).
@@ -585,7 +588,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 float phi = (2.0f * kPi) * rnd.y;                         // :412
                 float sphi, cphi;
                 dm::sincos_angle<Fast>(phi, rnd.y, sphi, cphi);
-                v3 l = normalize_unit_combination<Fast>(((su * cphi) * sin_a + (sv * sphi) * sin_a) + sw * cos_a);   // :413
+                v3 l = normalize_unit_combination<Fast, true>(((su * cphi) * sin_a + (sv * sphi) * sin_a) + sw * cos_a);   // :413
                 float tne;
                 bool reached;                                             // :420 shadow ray: is the nearest hit sphere i?
                 if constexpr (Slab) {
@@ -607,7 +610,9 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             v3 v = cross(w, u);
             float s1, c1;
             dm::sincos_angle<Fast>(r1, rnd.x, s1, c1);
-            rd = normalize_unit_combination<Fast>(((u * c1) * r2s + (v * s1) * r2s) + w * dm::fsqrt<Fast>(1.0f - r2));   // :428
+            // (w = +-n is of unit length in the slab kernels only: +-1 axis normals, normalised sphere normals; a generic scene's
+            // plane normal is used as given, and there :428's normalize is not an identity)
+            rd = normalize_unit_combination<Fast, Slab>(((u * c1) * r2s + (v * s1) * r2s) + w * dm::fsqrt<Fast>(1.0f - r2));   // :428
             ro = x;
             emissive = 0.0f;                                              // :429
         } else if (mat == 2) {                                            // :432 mirror
@@ -627,7 +632,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             if (cos2t >= 0.0f) {
                 MC_REGION(7);   // glass: refraction branch
                 float k = (into ? 1.0f : -1.0f) * (ddn * nnt + dm::fsqrt<Fast>(cos2t));
-                v3 tdir = normalize_unit_combination<Fast>(rd * nnt - n * k);   // :441 (unit by Snell's law)
+                v3 tdir = normalize_unit_combination<Fast, Slab>(rd * nnt - n * k);   // :441 (unit by Snell's law when rd, n are)
                 float aa = nt - nc, bb = nt + nc;
                 float R0 = dm::fdiv<Fast>(aa * aa, bb * bb);              // :442
                 float c = 1.0f - (into ? -ddn : dot(tdir, n));
