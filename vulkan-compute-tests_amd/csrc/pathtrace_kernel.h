@@ -615,36 +615,38 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             rd = normalize_unit_combination<Fast, Slab>(((u * c1) * r2s + (v * s1) * r2s) + w * dm::fsqrt<Fast>(1.0f - r2));   // :428
             ro = x;
             emissive = 0.0f;                                              // :429
-        } else if (mat == 2) {                                            // :432 mirror
-            MC_REGION(5);   // mirror
-            rd = reflect(rd, n);
-            ro = x;
-            emissive = 1.0f;
-        } else if (mat == 3) {                                            // :437 glass
+        } else if (mat == 2 || mat == 3) {                                // :432 mirror, :437 glass
+            // one block for both specular materials: the glass branch needs reflect(rd, n) (:444, :446) — the mirror's whole
+            // bounce (:433) — so a wave that holds lanes of both kinds evaluates it once
             MC_PT_DECISION_FP
-            MC_REGION(6);   // glass
-            bool into = (n.x == nl.x) && (n.y == nl.y) && (n.z == nl.z);  // :438
-            const float nc = 1.0f, nt = 1.5f;
-            float nnt = into ? dm::fdiv<Fast>(nc, nt) : dm::fdiv<Fast>(nt, nc);   // :439
-            float ddn = dot(rd, nl);
-            float cos2t = 1.0f - (nnt * nnt) * (1.0f - ddn * ddn);        // :440
-            v3 refl = reflect(rd, n);
-            if (cos2t >= 0.0f) {
-                MC_REGION(7);   // glass: refraction branch
-                float k = (into ? 1.0f : -1.0f) * (ddn * nnt + dm::fsqrt<Fast>(cos2t));
-                v3 tdir = normalize_unit_combination<Fast, Slab>(rd * nnt - n * k);   // :441 (unit by Snell's law when rd, n are)
-                float aa = nt - nc, bb = nt + nc;
-                float R0 = dm::fdiv<Fast>(aa * aa, bb * bb);              // :442
-                float c = 1.0f - (into ? -ddn : dot(tdir, n));
-                float Re = R0 + (((((1.0f - R0) * c) * c) * c) * c) * c;  // :443
-                float Tr = 1.0f - Re;
-                float P = 0.25f + 0.5f * Re;
-                float RP = dm::fdiv<Fast>(Re, P), TP = dm::fdiv<Fast>(Tr, 1.0f - P);
-                bool pick_refl = rnd.x < P;
-                rd = select(pick_refl, refl, tdir);                       // :444
-                accmat = accmat * (pick_refl ? RP : TP);                  // :445
+            MC_REGION(5);   // mirror direction = the glass block's reflected direction
+            const v3 refl = reflect(rd, n);
+            if (mat == 3) {
+                MC_REGION(6);   // glass
+                bool into = (n.x == nl.x) && (n.y == nl.y) && (n.z == nl.z);  // :438
+                const float nc = 1.0f, nt = 1.5f;
+                float nnt = into ? dm::fdiv<Fast>(nc, nt) : dm::fdiv<Fast>(nt, nc);   // :439
+                float ddn = dot(rd, nl);
+                float cos2t = 1.0f - (nnt * nnt) * (1.0f - ddn * ddn);        // :440
+                if (cos2t >= 0.0f) {
+                    MC_REGION(7);   // glass: refraction branch
+                    float k = (into ? 1.0f : -1.0f) * (ddn * nnt + dm::fsqrt<Fast>(cos2t));
+                    v3 tdir = normalize_unit_combination<Fast, Slab>(rd * nnt - n * k);   // :441 (unit by Snell's law when rd, n are)
+                    float aa = nt - nc, bb = nt + nc;
+                    float R0 = dm::fdiv<Fast>(aa * aa, bb * bb);              // :442
+                    float c = 1.0f - (into ? -ddn : dot(tdir, n));
+                    float Re = R0 + (((((1.0f - R0) * c) * c) * c) * c) * c;  // :443
+                    float Tr = 1.0f - Re;
+                    float P = 0.25f + 0.5f * Re;
+                    float RP = dm::fdiv<Fast>(Re, P), TP = dm::fdiv<Fast>(Tr, 1.0f - P);
+                    bool pick_refl = rnd.x < P;
+                    rd = select(pick_refl, refl, tdir);                       // :444
+                    accmat = accmat * (pick_refl ? RP : TP);                  // :445
+                } else {
+                    rd = refl;                                                // :446
+                }
             } else {
-                rd = refl;                                                // :446
+                rd = refl;                                                    // :433
             }
             ro = x;
             emissive = 1.0f;                                              // :447
