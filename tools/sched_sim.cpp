@@ -316,6 +316,54 @@ void sim_streams(const Tile& t, int pix0, int spp, int max_depth, const Cost& c,
     }
 }
 
+
+// ---------------------------------------------------------------- rounds kernel + ONE survivor merge per round
+// The round-synchronous kernel as it is (4 waves of a block, each 4 pixels x 16 samples), plus: at the start of depth `md` the
+// waves of a pair (w, w^1) exchange path states through LDS so that the survivors of both fill wave w first; wave w^1 keeps
+// only the overflow (usually nothing) and sleeps at the round's barrier.  One exchange of a 19-dword state per round and
+// migrating path instead of one per bounce (the regrouping kernel of round 2).  Results return through LDS for the ordered fold.
+void sim_merge_rounds(const Tile& t, int pixels, int spp, int max_depth, const Cost& c, int md, double ov_merge, Stats& st) {
+    for (int p0 = 0; p0 + 16 <= pixels; p0 += 16) {          // a block = 16 pixels = 4 waves
+        for (int base = 0; base < spp; base += 16) {
+            struct L { const std::vector<uint8_t>* ev; int pos; bool alive; };
+            std::vector<L> wave[4];
+            for (int w = 0; w < 4; w++)
+                for (int l = 0; l < 64; l++) {
+                    int p = p0 + 4 * w + l / 16, s2 = base + l % 16;
+                    L x; x.alive = s2 < spp; x.ev = x.alive ? &t.samples[(size_t)p * spp + s2] : nullptr; x.pos = 0;
+                    wave[w].push_back(x);
+                    if (x.alive) st.n_samples++;
+                }
+            for (int w = 0; w < 4; w++) { st.cost += c.cam + c.fold_round; st.useful += c.cam + c.fold_round; }
+            for (int depth = 0; depth < max_depth; depth++) {
+                if (depth == md) {
+                    for (int w = 0; w < 4; w += 2) {
+                        std::vector<L> surv;
+                        for (int ww = w; ww < w + 2; ww++) for (auto& x : wave[ww]) if (x.alive) surv.push_back(x);
+                        for (int ww = w; ww < w + 2; ww++) { wave[ww].assign(64, L{nullptr, 0, false}); }
+                        for (size_t i = 0; i < surv.size(); i++) wave[w + (i >= 64)][i % 64] = surv[i];
+                        st.cost += 2 * ov_merge;
+                    }
+                }
+                for (int w = 0; w < 4; w++) {
+                    int na = 0, nd = 0, ng = 0, nm = 0;
+                    for (auto& x : wave[w]) {
+                        if (!x.alive) continue;
+                        na++;
+                        if (x.pos >= (int)x.ev->size()) { x.alive = false; continue; }
+                        int e = (*x.ev)[x.pos++];
+                        if (e == 0) x.alive = false; else if (e == 1) nd++; else if (e == 2) nm++; else ng++;
+                    }
+                    if (!na) continue;
+                    st.iters += 0.25;
+                    st.cost += c.ip + (nd ? c.d : 0) + (ng ? c.g : 0) + (nm ? c.m : 0);
+                    st.useful += (na * c.ip + nd * c.d + ng * c.g + nm * c.m) / 64.0;
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- rounds kernel with samples SORTED by path length
 // Within a window of `window` consecutive samples of each pixel the samples are traced in order of (predicted) path length,
 // 16 per pixel and round, so that a round's lanes finish together; the ordered fold then needs the window's results in
@@ -431,6 +479,13 @@ int main(int argc, char** argv) {
                 printf("streams S=%2d lookahead=%10d stash=%d : cost/sample %7.1f (%.3fx)  lanes %.3f  iters/64samples %.2f\n", S, la, stash,
                        s.cost / s.n_samples, (base.cost / base.n_samples) / (s.cost / s.n_samples), s.useful / s.cost, s.iters * 64.0 / s.n_samples);
             }
+    for (int md : {7, 8, 9, 10, 11})
+        for (double ov : {0.0, 60.0, 100.0}) {
+            Stats s;
+            for (auto& t : tiles) sim_merge_rounds(t, pixels, spp, max_depth, c, md, ov, s);
+            printf("rounds + pair merge at depth %2d, overhead %3.0f/wave : cost/sample %7.1f (%.3fx)  lanes %.3f  iters/64samples %.2f\n", md, ov,
+                   s.cost / s.n_samples, (base.cost / base.n_samples) / (s.cost / s.n_samples), s.useful / s.cost, s.iters * 64.0 / s.n_samples);
+        }
     if (only_streams) return 0;
     struct Named { const char* name; RegroupCfg cfg; };
     std::vector<Named> cfgs;
