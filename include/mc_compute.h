@@ -215,6 +215,9 @@ int mc_multi_pathtrace_render_rgba8(mc_multi* m, const mc_pathtrace_params* p, c
 /* fn: 0 mc_sin, 1 mc_cos, 2 mc_log2, 3 mc_exp2, 4 pow(x,0.45), 5 inversesqrt, 6 sqrt, 7 1/x,
  * 8/9 sin/cos via the fused mc_sincos; fast=1 evaluates the MC_PT_MATH_FAST variants instead. */
 int mc_test_math(mc_context* ctx, int fn, int fast, const float* in, float* out, size_t n);
+/* Strict (a[3i], a[3i+1], a[3i+2]) / s[i] as the path tracer divides a colour by a probability, by pi, by the sample count (short
+ * division inside its window, IEEE expansion outside); with_y != 0: the reciprocal RN(1/s) is supplied instead of computed. */
+int mc_test_div3(mc_context* ctx, int with_y, const float* a, const float* s, float* out, size_t n);
 /* Strict fn 5 / 6 / 7 (and the guarded short reciprocal) over EVERY fp32 bit pattern first_bits .. first_bits+count-1, compared on
  * the device with the compiler's IEEE expansion: *mismatches (NaN == NaN), *checksum = sum of (result_bits ^ (bits * 0x9E3779B1))
  * mod 2^64 for a host-side comparison, *first_mismatch = lowest offending pattern (0xffffffff if none). */

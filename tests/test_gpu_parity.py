@@ -108,6 +108,36 @@ def test_short_forms_exhaustive(ctx, fn):
     assert chk == want % (1 << 64), fn
 
 
+@pytest.mark.parametrize("with_y", [False, True])
+def test_strict_shared_divisor_division_bit_exact(ctx, with_y):
+    """(a0, a1, a2) / s of the strict path tracer (Russian roulette, / pi, / spp): 3-instruction short division inside
+    [2^-60, 2^60) — proved over all 2^46 mantissa pairs by tools/exact_div_exhaustive.hip — and the IEEE expansion outside.
+    Here: the seams.  Random mantissas at every exponent pair around the window's edges, zeros of both signs, denormals, inf,
+    NaN, negative operands, numerators mixed across the window in one triple, mantissas 1.0 and 2 - ulp."""
+    rng = np.random.default_rng(21)
+    n = 400000
+    def rnd(n, emin, emax):
+        return (rng.uniform(1.0, 2.0, n) * 2.0 ** rng.integers(emin, emax + 1, n)).astype(np.float32)
+    a = rnd(3 * n, -70, 70).reshape(n, 3)
+    s = rnd(n, -70, 70)
+    a[: n // 4] = rnd(3 * (n // 4), -20, 6).reshape(-1, 3)          # what the kernel sees: colours, probabilities
+    s[: n // 4] = rnd(n // 4, -3, 2)
+    a[n // 2: 3 * n // 4] = rnd(3 * (n // 4), -60, 59).reshape(-1, 3)   # the whole window: every wave takes the short form
+    s[n // 2: 3 * n // 4] = rnd(n // 4, -60, 59)
+    a[n // 2: n // 2 + n // 16, 1] = 0.0                                 # ... also with +0 numerators
+    special = np.array([0.0, -0.0, 1e-40, -1e-40, np.inf, -np.inf, np.nan, 1.0, -1.0, 2.0 ** -60, 2.0 ** 60, 2.0 ** -61,
+                        np.float32(2.0) - np.float32(2.0 ** -23), 3.1415927, 500.0, 1e-45], np.float32)
+    k = rng.integers(0, len(special), (n // 8, 3))
+    a[n // 4: n // 4 + n // 8] = special[k]
+    s[n // 4 + n // 16: n // 4 + n // 8] = special[rng.integers(0, len(special), n // 16)]
+    with np.errstate(all="ignore"):
+        want = a / s[:, None]
+    got = ctx.test_div3(a, s, with_y=with_y)
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(bits(got)[~nan], bits(want)[~nan])
+
+
 def test_fast_math_within_a_few_ulp(ctx):
     x = np.random.default_rng(6).uniform(1e-3, 1e3, 100000).astype(np.float32)
     for fn, ref in (("sqrt", np.sqrt(x.astype(np.float64))), ("rcp", 1.0 / x.astype(np.float64)),

@@ -1,0 +1,17 @@
+import sys, os, time, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+import __graft_entry__ as entry
+B = entry.load_package().bindings
+W, H, spp = 900, 600, 500
+ctx = B.Context(0)
+st = torch.cuda.Stream(); torch.cuda.set_stream(st); s = st.cuda_stream
+buf = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+p = B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_STRICT)
+for _ in range(2): ctx.pathtrace_device(p, buf.data_ptr(), stream=s)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5): ctx.pathtrace_device(p, buf.data_ptr(), stream=s)
+e1.record(); torch.cuda.synchronize()
+import hashlib
+print(os.environ.get("MC_LIB_PATH","default"), "MS", e0.elapsed_time(e1) / 5, hashlib.sha1(buf.cpu().numpy().tobytes()).hexdigest()[:12])

@@ -103,6 +103,7 @@ def lib():
         L.mc_multi_mandelbrot_render.argtypes = [vp, C.POINTER(MandelbrotParams), vp, vp]
         L.mc_multi_pathtrace_render.argtypes = [vp, C.POINTER(PathtraceParams), vp, u32, vp, u32, vp]
         L.mc_test_math.argtypes = [vp, i32, i32, vp, vp, C.c_size_t]
+        L.mc_test_div3.argtypes = [vp, i32, vp, vp, vp, C.c_size_t]
         L.mc_test_math_sweep.argtypes = [vp, i32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint32)]
         L.mc_test_rand01.argtypes = [vp, vp, vp, C.c_size_t]
@@ -283,6 +284,13 @@ class Context:
         x = np.ascontiguousarray(x, np.float32).reshape(-1)
         out = np.empty_like(x)
         _check(lib().mc_test_math(self._h, code, int(fast), _ptr(x), _ptr(out), x.size), "mc_test_math")
+        return out
+
+    def test_div3(self, a, s, with_y=False):
+        a = np.ascontiguousarray(a, np.float32).reshape(-1, 3)
+        s = np.ascontiguousarray(s, np.float32).reshape(-1)
+        out = np.empty_like(a)
+        _check(lib().mc_test_div3(self._h, int(with_y), _ptr(a), _ptr(s), _ptr(out), s.size), "mc_test_div3")
         return out
 
     def test_math_sweep(self, fn, first_bits, count):

@@ -498,6 +498,27 @@ int mc_test_math(mc_context* ctx, int fn, int fast, const float* in, float* out,
                     n, fn, fast);
 }
 
+// strict (a0, a1, a2) / s through dm::div3 (short division inside its window, IEEE expansion outside); with_y: y = RN(1/s) supplied
+__global__ void test_div3_kernel(int with_y, const float* __restrict__ a, const float* __restrict__ sv, float* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a0 = a[3 * i], a1 = a[3 * i + 1], a2 = a[3 * i + 2];
+    const float s = sv[i];
+    if (with_y) dm::div3<false, true>(a0, a1, a2, s, dm::ieee_div(1.0f, s));
+    else dm::div3<false, false>(a0, a1, a2, s, 0.0f);
+    out[3 * i] = a0; out[3 * i + 1] = a1; out[3 * i + 2] = a2;
+}
+
+int mc_test_div3(mc_context* ctx, int with_y, const float* a, const float* s, float* out, size_t n) {
+    if (!ctx || !a || !s || !out || !n) return MC_ERR_INVALID_ARGUMENT;
+    return run_test(ctx, a, n * 12, s, n * 4, out, n * 12,
+                    [](void* x, void* y, void* o, size_t n_, hipStream_t st, int with_y_, int) {
+                        hipLaunchKernelGGL(test_div3_kernel, dim3((unsigned)((n_ + 255) / 256)), dim3(256), 0, st, with_y_,
+                                           (const float*)x, (const float*)y, (float*)o, n_);
+                    },
+                    n, with_y, 0);
+}
+
 // Every bit pattern first_bits .. first_bits + count - 1: strict device function vs the compiler's IEEE expansion.
 __global__ void test_math_sweep_kernel(int fn, uint32_t first_bits, unsigned long long count, unsigned long long* res) {
     unsigned long long bad = 0, sum = 0;

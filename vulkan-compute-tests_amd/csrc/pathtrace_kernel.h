@@ -100,9 +100,14 @@ __device__ __forceinline__ v3 cross(v3 a, v3 b) {
     return v3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
 }
 template <bool Fast> __device__ __forceinline__ v3 normalize(v3 a) { return a * dm::inversesqrt<Fast>(dot(a, a)); }
-template <bool Fast> __device__ __forceinline__ v3 divs(v3 a, float s) {
-    return v3{dm::fdiv<Fast>(a.x, s), dm::fdiv<Fast>(a.y, s), dm::fdiv<Fast>(a.z, s)};
+// a / s, three numerators over one divisor.  Strict: the short division of mc_math.h inside its window (wave-wide test),
+// the compiler's IEEE expansion outside.  divs_recip: the caller supplies y = RN(1/s) (a constant, a host-computed argument).
+template <bool Fast, bool HaveY> __device__ __forceinline__ v3 divs_impl(v3 a, float s, float y) {
+    dm::div3<Fast, HaveY>(a.x, a.y, a.z, s, y);
+    return a;
 }
+template <bool Fast> __device__ __forceinline__ v3 divs(v3 a, float s) { return divs_impl<Fast, false>(a, s, 0.0f); }
+template <bool Fast> __device__ __forceinline__ v3 divs_recip(v3 a, float s, float y) { return divs_impl<Fast, true>(a, s, y); }
 // First tangent of the orthonormal basis around w (:409, :427): normalize(cross(|w.x| > 0.1 ? (0,1,0) : (1,0,0), w)).
 // Strict: the literal expression (its products with the axis' zeros decide the sign of zero components).
 // Fast (toleranced): the cross product is (w.z, 0, -w.x) or (0, -w.z, w.y) — one select, one fused squared length, two
@@ -216,6 +221,8 @@ static __device__ unsigned long long g_region_lanes[16];
 
 constexpr float kEps = 1e-4f, kTriEps = 1e-7f, kInf = 1e20f;   // pathTracer.comp:103-105
 constexpr float kPi = 3.141592653589793f;                       // :102
+constexpr float kInvPi = 1.0f / kPi;                            // RN(1 / kPi): the y of dm::div_step for :422's accmat / pi
+static_assert(kInvPi == 0x1.45f306p-2f, "1/pi must be the correctly rounded fp32 quotient (numpy: float32(1)/float32(pi) = 0x3ea2f983)");
 
 // ---- extended-precision sphere test (pathTracer.comp:132-256; every variant is compiled OUT in the reference's
 // default build, emulateDouble.h.glsl:13-26).  Prec: 1 = USE_NATIVE_FP64 (:139-142), 2 = DS_f32_f32 (:151-204),
@@ -564,6 +571,11 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
         if (mat == 1) {                                                   // :400 diffuse
             MC_REGION(3);   // diffuse: NEE set-up + shadow ray
             const int n_lights = LdsScene ? (int)sc.n_emissive : ns;
+            // :422's accmat / pi.  Strict: formed here, once per diffuse bounce, not inside the `reached` block of every light —
+            // the guarded short division's never-taken IEEE branch in that innermost block cost 3 ms at K2 (measured), here nothing;
+            // the quotient of a light that is not reached is simply not used.
+            v3 accmat_over_pi{0.0f, 0.0f, 0.0f};
+            if constexpr (!Fast) accmat_over_pi = divs_recip<Fast>(accmat, kPi, kInvPi);
 #pragma unroll
             for (int k = 0; k < (Slab ? 3 : n_lights); k++) {             // :403 (slab: unrolled, the index is a constant)
                 int i = k;
@@ -600,7 +612,8 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 if (reached) {
                     MC_REGION(4);   // shadow ray reached the light
                     float omega = (2.0f * kPi) * (1.0f - cos_a_max);      // :421
-                    accrad = accrad + ((divs<Fast>(accmat, kPi) * dm::gmax(dot(l, nl), 0.0f)) * le) * omega;   // :422
+                    if constexpr (Fast) accmat_over_pi = divs_recip<Fast>(accmat, kPi, kInvPi);
+                    accrad = accrad + ((accmat_over_pi * dm::gmax(dot(l, nl), 0.0f)) * le) * omega;   // :422
                 }
             }
             MC_REGION(8);   // diffuse bounce direction
@@ -726,7 +739,7 @@ __global__ void __launch_bounds__(256, Fast ? 6 : 5) pathtrace_kernel(PTArgs a) 
         v3 q{0.0f, 0.0f, 0.0f};
         if (c.valid && s < a.sample_end) {
             v3 rad = trace_sample<Fast, NP, NS, Slab, Prec>(a, lds_obj, lds_emissive, hot, c.gx, c.gy, s);
-            q = Fast ? rad * a.inv_spp : divs<Fast>(rad, fspp);                 // :452 accrad / samps.y
+            q = Fast ? rad * a.inv_spp : divs_recip<Fast>(rad, fspp, a.inv_spp);      // :452 accrad / samps.y (inv_spp = RN(1/spp), host)
         }
         // fold the round's S samples into the accumulator in sample order (every lane of the group
         // performs the same additions, so all S copies of acc stay identical)

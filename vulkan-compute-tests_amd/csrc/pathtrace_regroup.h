@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(64 * NW, 6) pathtrace_regroup_kernel(PTArgs a)
                                                                : intersect_slab<Fast>(hot, x, l, tne, false) == NP + i;
                 if (reached) {
                     float omega = (2.0f * kPi) * (1.0f - cos_a_max);          // :421
-                    P.accrad = P.accrad + ((divs<Fast>(P.accmat, kPi) * dm::gmax(dot(l, nl), 0.0f)) * le) * omega;   // :422
+                    P.accrad = P.accrad + ((divs_recip<Fast>(P.accmat, kPi, kInvPi) * dm::gmax(dot(l, nl), 0.0f)) * le) * omega;   // :422
                 }
             }
             float r1 = (2.0f * kPi) * P.rx, r2 = P.ry, r2s = dm::fsqrt<Fast>(r2);   // :426
