@@ -497,8 +497,10 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
     // -- sample sensor (:357-362)
     v3 r0 = rand01(gx, gy, samp);
     float rnd2x = 2.0f * r0.x, rnd2y = 2.0f * r0.y;
-    float tentx = rnd2x < 1.0f ? dm::fsqrt<Fast>(rnd2x) - 1.0f : 1.0f - dm::fsqrt<Fast>(2.0f - rnd2x);
-    float tenty = rnd2y < 1.0f ? dm::fsqrt<Fast>(rnd2y) - 1.0f : 1.0f - dm::fsqrt<Fast>(2.0f - rnd2y);
+    // :358-:359 tent filter: one sqrt of the selected argument instead of one per branch (the same value either way)
+    const float sqx = dm::fsqrt<Fast>(rnd2x < 1.0f ? rnd2x : 2.0f - rnd2x), sqy = dm::fsqrt<Fast>(rnd2y < 1.0f ? rnd2y : 2.0f - rnd2y);
+    float tentx = rnd2x < 1.0f ? sqx - 1.0f : 1.0f - sqx;
+    float tenty = rnd2y < 1.0f ? sqy - 1.0f : 1.0f - sqy;
     float stratx = (float)((samp / 2u) % 2u), straty = (float)(samp % 2u);
     const float px = (float)gx + 0.5f * ((0.5f + stratx) + tentx), py = (float)gy + 0.5f * ((0.5f + straty) + tenty);
     float sx = ((Fast ? px * a.inv_W : dm::fdiv<Fast>(px, (float)a.W)) - 0.5f) * 0.036f;
@@ -643,18 +645,21 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 float cos2t = 1.0f - (nnt * nnt) * (1.0f - ddn * ddn);        // :440
                 if (cos2t >= 0.0f) {
                     MC_REGION(7);   // glass: refraction branch
-                    float k = (into ? 1.0f : -1.0f) * (ddn * nnt + dm::fsqrt<Fast>(cos2t));
+                    const float sq2t = dm::fsqrt<Fast>(cos2t);
+                    float k = (into ? 1.0f : -1.0f) * (ddn * nnt + sq2t);
                     v3 tdir = normalize_unit_combination<Fast, Slab>(rd * nnt - n * k);   // :441 (unit by Snell's law when rd, n are)
                     float aa = nt - nc, bb = nt + nc;
                     float R0 = dm::fdiv<Fast>(aa * aa, bb * bb);              // :442
-                    float c = 1.0f - (into ? -ddn : dot(tdir, n));
+                    // fast: dot(tdir, n) of the leaving ray is sqrt(cos2t) in exact arithmetic (tdir = rd*nnt - n*k, n = -nl)
+                    float c = 1.0f - (into ? -ddn : (Fast && Slab ? sq2t : dot(tdir, n)));
                     float Re = R0 + (((((1.0f - R0) * c) * c) * c) * c) * c;  // :443
                     float Tr = 1.0f - Re;
                     float P = 0.25f + 0.5f * Re;
-                    float RP = dm::fdiv<Fast>(Re, P), TP = dm::fdiv<Fast>(Tr, 1.0f - P);
                     bool pick_refl = rnd.x < P;
+                    // :442's RP = Re / P and TP = Tr / (1 - P): only the one :445 uses is formed (the same quotient)
+                    const float weight = dm::fdiv<Fast>(pick_refl ? Re : Tr, pick_refl ? P : 1.0f - P);
                     rd = select(pick_refl, refl, tdir);                       // :444
-                    accmat = accmat * (pick_refl ? RP : TP);                  // :445
+                    accmat = accmat * weight;                                 // :445
                 } else {
                     rd = refl;                                                // :446
                 }
