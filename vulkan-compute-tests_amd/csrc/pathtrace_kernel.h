@@ -602,7 +602,9 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 float phi = (2.0f * kPi) * rnd.y;                         // :412
                 float sphi, cphi;
                 dm::sincos_angle<Fast>(phi, rnd.y, sphi, cphi);
-                v3 l = normalize_unit_combination<Fast, true>(((su * cphi) * sin_a + (sv * sphi) * sin_a) + sw * cos_a);   // :413
+                // fast: the two scalar factors of a tangent are multiplied first (u*(c*s) for (u*c)*s: one product less per component)
+                v3 l = Fast ? (su * (cphi * sin_a) + sv * (sphi * sin_a)) + sw * cos_a
+                            : normalize_unit_combination<Fast, true>(((su * cphi) * sin_a + (sv * sphi) * sin_a) + sw * cos_a);   // :413
                 float tne;
                 bool reached;                                             // :420 shadow ray: is the nearest hit sphere i?
                 if constexpr (Slab) {
@@ -614,8 +616,12 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 if (reached) {
                     MC_REGION(4);   // shadow ray reached the light
                     float omega = (2.0f * kPi) * (1.0f - cos_a_max);      // :421
-                    if constexpr (Fast) accmat_over_pi = divs_recip<Fast>(accmat, kPi, kInvPi);
-                    accrad = accrad + ((accmat_over_pi * dm::gmax(dot(l, nl), 0.0f)) * le) * omega;   // :422
+                    if constexpr (Fast) {   // the three scalar factors of :422 are multiplied first
+                        const float scale = (__builtin_fmaxf(dot(l, nl), 0.0f) * omega) * kInvPi;
+                        accrad = accrad + (accmat * le) * scale;
+                    } else {
+                        accrad = accrad + ((accmat_over_pi * dm::gmax(dot(l, nl), 0.0f)) * le) * omega;   // :422
+                    }
                 }
             }
             MC_REGION(8);   // diffuse bounce direction
@@ -627,7 +633,8 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             dm::sincos_angle<Fast>(r1, rnd.x, s1, c1);
             // (w = +-n is of unit length in the slab kernels only: +-1 axis normals, normalised sphere normals; a generic scene's
             // plane normal is used as given, and there :428's normalize is not an identity)
-            rd = normalize_unit_combination<Fast, Slab>(((u * c1) * r2s + (v * s1) * r2s) + w * dm::fsqrt<Fast>(1.0f - r2));   // :428
+            rd = Fast ? normalize_unit_combination<Fast, Slab>((u * (c1 * r2s) + v * (s1 * r2s)) + w * dm::fsqrt<Fast>(1.0f - r2))
+                      : normalize_unit_combination<Fast, Slab>(((u * c1) * r2s + (v * s1) * r2s) + w * dm::fsqrt<Fast>(1.0f - r2));   // :428
             ro = x;
             emissive = 0.0f;                                              // :429
         } else if (mat == 2 || mat == 3) {                                // :432 mirror, :437 glass
