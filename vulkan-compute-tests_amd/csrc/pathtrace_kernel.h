@@ -381,6 +381,7 @@ __device__ __forceinline__ bool shadow_reaches_sphere(const HotSlab& h, v3 o, v3
         dd[i] = r;
     }
     // li is a constant of the caller's unrolled light loop
+    if (Fast && li == 2) return dd[2] < __builtin_fminf(dd[0], dd[1]);   // the same test for ordered values (dd <= 1e20)
     if (li == 2) return dd[2] < dd[0] && dd[2] < dd[1] && dd[2] < h.inf;
     if (li == 1) return dd[1] < dd[0] && !(dd[2] < dd[1]) && dd[1] < h.inf;
     return !(dd[1] < dd[0]) && !(dd[2] < dd[0]) && dd[0] < h.inf;
@@ -549,10 +550,12 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
         // (fast mode keeps this normalize: a grazing hit's t = b - sqrt(det) cancels, x leaves the sphere by far more than an
         // ulp and (x - c) / r is visibly wrong: rmse 0.40 / p99.9 7.4 against the 0.5 / 4 bound, measured)
         v3 n = is_sphere ? normalize<Fast>(x - geo) : geo;                // :381/:387
+        float dot_n_rd = 0.0f;                                            // fast: kept for the glass block
         v3 nl;                                                            // :390 nl = dot(n, rd) < 0 ? n : -n
         if constexpr (Fast) {   // the sign bit of the dot product, inverted, flips n: 5 two-cycle integer operations instead of a
                                 // compare and three selects (differs from `<` only for a dot product of exactly -0)
-            const uint32_t flip = ~dm::as_uint(dot(n, rd)) & 0x80000000u;
+            dot_n_rd = dot(n, rd);
+            const uint32_t flip = ~dm::as_uint(dot_n_rd) & 0x80000000u;
             nl = v3{dm::as_float(dm::as_uint(n.x) ^ flip), dm::as_float(dm::as_uint(n.y) ^ flip), dm::as_float(dm::as_uint(n.z) ^ flip)};
         } else {
             nl = dot(n, rd) < 0.0f ? n : -n;
@@ -616,8 +619,8 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 if (reached) {
                     MC_REGION(4);   // shadow ray reached the light
                     float omega = (2.0f * kPi) * (1.0f - cos_a_max);      // :421
-                    if constexpr (Fast) {   // the three scalar factors of :422 are multiplied first
-                        const float scale = (__builtin_fmaxf(dot(l, nl), 0.0f) * omega) * kInvPi;
+                    if constexpr (Fast) {   // the scalar factors of :422 are multiplied first; omega / pi = 2 (1 - cos_a_max)
+                        const float scale = __builtin_fmaxf(dot(l, nl), 0.0f) * (2.0f - (cos_a_max + cos_a_max));
                         accrad = accrad + (accmat * le) * scale;
                     } else {
                         accrad = accrad + ((accmat_over_pi * dm::gmax(dot(l, nl), 0.0f)) * le) * omega;   // :422
@@ -645,10 +648,11 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             const v3 refl = reflect(rd, n);
             if (mat == 3) {
                 MC_REGION(6);   // glass
-                bool into = (n.x == nl.x) && (n.y == nl.y) && (n.z == nl.z);  // :438
+                // fast: nl is n exactly when dot(n, rd) carries a sign bit, and dot(rd, nl) is then -|dot(n, rd)|
+                bool into = Fast ? (dm::as_uint(dot_n_rd) >> 31) != 0u : (n.x == nl.x) && (n.y == nl.y) && (n.z == nl.z);  // :438
                 const float nc = 1.0f, nt = 1.5f;
                 float nnt = into ? dm::fdiv<Fast>(nc, nt) : dm::fdiv<Fast>(nt, nc);   // :439
-                float ddn = dot(rd, nl);
+                float ddn = Fast ? -__builtin_fabsf(dot_n_rd) : dot(rd, nl);
                 float cos2t = 1.0f - (nnt * nnt) * (1.0f - ddn * ddn);        // :440
                 if (cos2t >= 0.0f) {
                     MC_REGION(7);   // glass: refraction branch
