@@ -573,6 +573,9 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             if (rnd.z >= p) break;                                        // :396
             accmat = divs<Fast>(accmat, p);                               // :397
         }
+        // every material 1..3 continues from x (:429,:434,:447): with all materials known (uniform) the assignment is made once,
+        // ahead of the dispatch, so that no branch has to copy it at the merge
+        if constexpr (Slab) { if (sc.materials_known) ro = x; }
         if (mat == 1) {                                                   // :400 diffuse
             MC_REGION(3);   // diffuse: NEE set-up + shadow ray
             const int n_lights = LdsScene ? (int)sc.n_emissive : ns;
@@ -638,7 +641,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             // plane normal is used as given, and there :428's normalize is not an identity)
             rd = Fast ? normalize_unit_combination<Fast, Slab>((u * (c1 * r2s) + v * (s1 * r2s)) + w * dm::fsqrt<Fast>(1.0f - r2))
                       : normalize_unit_combination<Fast, Slab>(((u * c1) * r2s + (v * s1) * r2s) + w * dm::fsqrt<Fast>(1.0f - r2));   // :428
-            ro = x;
+            if (!Slab || !sc.materials_known) ro = x;   // (slab scenes of known materials: moved ahead of the dispatch)
             emissive = 0.0f;                                              // :429
         } else if (mat == 2 || mat == 3) {                                // :432 mirror, :437 glass
             // one block for both specular materials: the glass branch needs reflect(rd, n) (:444, :446) — the mirror's whole
@@ -663,7 +666,9 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                     float R0 = dm::fdiv<Fast>(aa * aa, bb * bb);              // :442
                     // fast: dot(tdir, n) of the leaving ray is sqrt(cos2t) in exact arithmetic (tdir = rd*nnt - n*k, n = -nl)
                     float c = 1.0f - (into ? -ddn : (Fast && Slab ? sq2t : dot(tdir, n)));
-                    float Re = R0 + (((((1.0f - R0) * c) * c) * c) * c) * c;  // :443
+                    float Re;                                                 // :443 R0 + (1 - R0) c^5
+                    if constexpr (Fast) { const float c2 = c * c; Re = R0 + (1.0f - R0) * ((c2 * c2) * c); }   // c^5 through c^2, c^4
+                    else Re = R0 + (((((1.0f - R0) * c) * c) * c) * c) * c;
                     float Tr = 1.0f - Re;
                     float P = 0.25f + 0.5f * Re;
                     bool pick_refl = rnd.x < P;
@@ -677,7 +682,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             } else {
                 rd = refl;                                                    // :433
             }
-            ro = x;
+            if (!Slab || !sc.materials_known) ro = x;   // (slab scenes of known materials: moved ahead of the dispatch)
             emissive = 1.0f;                                              // :447
         }
         if constexpr (Slab) {
