@@ -648,6 +648,30 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             // bounce (:433) — so a wave that holds lanes of both kinds evaluates it once
             MC_PT_DECISION_FP
             MC_REGION(5);   // mirror direction = the glass block's reflected direction
+            if constexpr (Fast && Slab) {
+                // Fast slab form: every outcome is rd*alpha + n*beta — reflection (1, -2 dot(n, rd)), refraction (nnt, -k) — so
+                // the scalars are selected and ONE direction is formed; cos of the leaving ray = sqrt(cos2t), c^5 through c^2.
+                float alpha = 1.0f, beta = -2.0f * dot_n_rd;
+                if (mat == 3) {
+                    MC_REGION(6);
+                    const bool into = (dm::as_uint(dot_n_rd) >> 31) != 0u;            // :438 (nl == n)
+                    const float nnt = into ? 1.0f / 1.5f : 1.5f;                      // :439
+                    const float a_dn = __builtin_fabsf(dot_n_rd);                      // = -dot(rd, nl)
+                    const float cos2t = 1.0f - (nnt * nnt) * (1.0f - a_dn * a_dn);    // :440
+                    if (cos2t >= 0.0f) {
+                        MC_REGION(7);
+                        const float sq2t = dm::fsqrt<true>(cos2t);
+                        const float k = (into ? 1.0f : -1.0f) * (sq2t - a_dn * nnt);  // :441
+                        const float c = 1.0f - (into ? a_dn : sq2t), c2 = c * c;
+                        const float Re = 0.04f + 0.96f * ((c2 * c2) * c);              // :442-:443, R0 = (0.5/2.5)^2
+                        const float P = 0.25f + 0.5f * Re;
+                        const bool pick_refl = rnd.x < P;                             // :444
+                        accmat = accmat * dm::fdiv<true>(pick_refl ? Re : 1.0f - Re, pick_refl ? P : 1.0f - P);   // :445
+                        if (!pick_refl) { alpha = nnt; beta = -k; }
+                    }
+                }
+                rd = rd * alpha + n * beta;
+            } else {
             const v3 refl = reflect(rd, n);
             if (mat == 3) {
                 MC_REGION(6);   // glass
@@ -682,6 +706,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             } else {
                 rd = refl;                                                    // :433
             }
+            }   // (general form)
             if (!Slab || !sc.materials_known) ro = x;   // (slab scenes of known materials: moved ahead of the dispatch)
             emissive = 1.0f;                                              // :447
         }
