@@ -56,37 +56,67 @@ WORKLOAD_ALIAS = {"pathtrace": "K2", "mandelbrot": "K1", "mandelbrot_ds": "K1ds"
 PROFILE_TAG = {"K2": {"fast": "pt_fast", "strict": "pt_strict"}, "K1": "mandel", "K1ds": "mandel_ds"}
 
 
-def profiled_traffic(cfg_name, args, n):
-    """HBM bytes per STEP from the rocprofv3 PMC pass committed under profiles/ (WRITE_SIZE in its own --pmc pass, exact for
-    16-B-per-lane stores, MI355X_MICROARCH.md §HBM), summed over every launch of a step (a K2 step is two launches: the
-    S = 16 rounds and the 4-sample tail, which also re-reads the 8.64 MB accumulator it continues — added as algorithmic
-    bytes, FETCH_SIZE being uncalibrated for lane-sparse loads).  (None, None) when the run is not a profiled configuration."""
+PROFILE_ROUNDS = ("r03", "r02", "r01d", "r01c")
+
+
+def profiled_summary(cfg_name, args, n):
+    """The committed rocprofv3 PMC summary (profiles/<round>_<tag>_pmc_summary.json) of this exact configuration, newest round
+    first; None when the run is not a profiled configuration (N > 1, overridden sizes)."""
     if n != 1 or args.width or args.height or args.spp or cfg_name not in PROFILE_TAG:
         return None, None
     tag = PROFILE_TAG[cfg_name]
     if isinstance(tag, dict):
         tag = tag[args.math]
-    for rnd in ("r02", "r01d", "r01c"):
+    for rnd in PROFILE_ROUNDS:
         path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}_pmc_summary.json")
         if os.path.exists(path):
             try:
-                entries = json.load(open(path))
-                total, launches = 0.0, 0
-                for name, entry in entries.items():
-                    b = entry.get("derived", {}).get("hbm_write_bytes")
-                    if b and ("pathtrace_kernel" in name or "mandelbrot_kernel" in name):
-                        total += b
-                        launches += 1
-                if not launches:
-                    return None, None
-                note = f"profiles/{os.path.basename(path)}: WRITE_SIZE summed over the {launches} launch(es) of a step"
-                if cfg_name == "K2" and launches == 2:
-                    total += 900 * 600 * 16
-                    note += " + the tail launch's 8.64 MB accumulator read (algorithmic)"
-                return total, note
+                entries = {k: v for k, v in json.load(open(path)).items() if "pathtrace" in k or "mandelbrot_kernel" in k}
+                return (entries, os.path.basename(path)) if entries else (None, None)
             except (ValueError, OSError):
                 return None, None
     return None, None
+
+
+def profiled_traffic(cfg_name, args, n):
+    """HBM bytes per STEP from the rocprofv3 PMC pass committed under profiles/ (WRITE_SIZE in its own --pmc pass, exact for
+    16-B-per-lane stores, MI355X_MICROARCH.md §HBM), summed over every launch of a step (a K2 step may be two launches: the
+    S = 16 rounds and the 4-sample tail, which also re-reads the 8.64 MB accumulator it continues — added as algorithmic
+    bytes, FETCH_SIZE being uncalibrated for lane-sparse loads).  (None, None) when the run is not a profiled configuration."""
+    entries, fname = profiled_summary(cfg_name, args, n)
+    if not entries:
+        return None, None
+    total, launches = 0.0, 0
+    for entry in entries.values():
+        b = entry.get("derived", {}).get("hbm_write_bytes")
+        if b:
+            total += b
+            launches += 1
+    if not launches:
+        return None, None
+    note = f"profiles/{fname}: WRITE_SIZE summed over the {launches} launch(es) of a step"
+    if cfg_name == "K2" and launches == 2:
+        total += 900 * 600 * 16
+        note += " + the tail launch's 8.64 MB accumulator read (algorithmic)"
+    return total, note
+
+
+def profiled_executed_lane_flops(cfg_name, args, n):
+    """EXECUTED fp32 lane-flops per step from the committed PMC instruction mix: (add + mul + 2 fma + transcendental
+    wave-instructions) x the active lanes per VALU instruction, summed over the launches of a step.  This is what the ALUs
+    did, as opposed to the algorithmic count of the reference's arithmetic that `roofline.achieved` is defined on."""
+    entries, fname = profiled_summary(cfg_name, args, n)
+    if not entries:
+        return None, None
+    total = 0.0
+    for entry in entries.values():
+        c, d = entry.get("per_launch_mean", {}), entry.get("derived", {})
+        lanes = d.get("active_lanes_per_valu_inst")
+        if lanes is None or "SQ_INSTS_VALU_ADD_F32" not in c:
+            return None, None
+        total += (c["SQ_INSTS_VALU_ADD_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + 2.0 * c["SQ_INSTS_VALU_FMA_F32"] +
+                  c["SQ_INSTS_VALU_TRANS_F32"]) * lanes
+    return total, f"profiles/{fname}: (ADD + MUL + 2 FMA + TRANS wave-instructions) x active lanes per VALU instruction"
 
 
 def lavapipe_probe():
@@ -252,6 +282,7 @@ def main():
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_k0, ev_k1)]))
     sclk_mhz = ctx.measure_clock() if rank == 0 else None   # the clock this box holds under VALU load (boxes differ by >10 %)
     gather_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_k1, ev_g1)])) if n > 1 else 0.0
+    gather_bytes = int(tile.numel() * tile.element_size()) if n > 1 else 0   # what every rank sends to rank 0 per step
 
     # ---- units ------------------------------------------------------------------------------------
     if is_pt:
@@ -259,7 +290,7 @@ def main():
     else:
         it = iters_t[:rows_local].to(torch.int64)
         M = p.max_iter
-        local_units = int(torch.where(it < M, it + 1, torch.full_like(it, M)).sum().item())   # executed loop bodies
+        local_units = int(torch.where(it < M, it + 1, torch.full_like(it, M)).sum().item())   # loop bodies of the REFERENCE algorithm
         if n > 1:
             tot = torch.tensor([local_units], dtype=torch.int64, device="cuda")
             dist.all_reduce(tot)
@@ -301,11 +332,25 @@ def main():
         achieved_tflops = local_units * flops_per_unit / (kernel_ms * 1e-3) / 1e12
         kern = "pathtrace_kernel" if is_pt else ("mandelbrot_kernel<StateDS>" if cfg["ds"] else "mandelbrot_kernel<StateF32>")
         traffic, traffic_source = profiled_traffic(cfg_name, args, n)
-        bytes_per_pixel = 16 if is_pt else 20
-        if is_pt and n == 1 and (p.spp % 16) and p.spp > 16:
-            alg_bytes = W * rows_local * 16 * 3      # two launches: rounds (write), ragged tail (read + write)
+        exec_flops, exec_source = profiled_executed_lane_flops(cfg_name, args, n)
+        # the algorithmic bytes are the 16-B storage-buffer entry per pixel, written ONCE (the Mandelbrot kernel
+        # also writes its 4-B iteration count, the parity object).  More launches per step or an accumulator re-read show up
+        # in `traffic` (PMC) and in `traffic_ratio`, not here.
+        alg_bytes = W * rows_local * (16 if is_pt else 20)
+        peak_at_clock = cus * 4 * 32 * sclk_mhz * 1e6          # lane-ops/s at the clock this box held under VALU load
+        if is_pt and args.math == "fast":
+            note = ("fast math: hardware transcendentals, a*b+c contraction, identities of exact arithmetic not executed (toleranced "
+                    "parity); `achieved` counts the REFERENCE's arithmetic per sample, `executed` what the ALUs did; the strict "
+                    "kernel, reported beside it, forbids all three")
+        elif is_pt:
+            note = "parity forbids contraction: one issue slot per flop"
+        elif cfg["ds"]:
+            note = ("142 = the reference composition's literal flop count per pixel-iteration; the kernel gets the same bits from "
+                    "~87 issued instructions (Dekker error term = one fma, exact), so the lane-op fraction may exceed 1")
         else:
-            alg_bytes = W * rows_local * bytes_per_pixel
+            note = ("pixel-iters are loop bodies of the REFERENCE algorithm (n + 1 per escaping pixel, M per interior pixel): converged "
+                    "tiles leave early through exact cycle detection, so `achieved` is reference-equivalent work per second and may "
+                    "exceed the issue ceiling; `executed` is the arithmetic that actually ran")
         out = {
             "metric": metric, "value": value, "unit": unit, "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
@@ -313,8 +358,9 @@ def main():
             "config": {"workload": workload_name, "baseline_config": cfg_name, "image": [W, H], "rows_per_gpu": rows_local,
                        "tiling": "whole image" if n == 1 else f"interleaved {ROW_BLOCK}-row blocks, RCCL gather to rank 0",
                        "device": dev_name, "compute_units": cus, "sclk_mhz_under_valu_load": round(sclk_mhz, 1),
+                       **({"unit_note": "reference-equivalent pixel-iterations (see roofline.lane_ops.note)"} if not is_pt else {}),
                        **({"backend": backend, "world_size": dist.get_world_size(), "ranks": ranks_info,
-                           "gather_ms_rank0": round(gather_ms, 4),
+                           "gather_ms_rank0": round(gather_ms, 4), "gather_bytes_per_rank": gather_bytes,
                            "gather_note": "kernel end -> gathered + re-assembled on rank 0; includes waiting for the slowest rank"}
                           if n > 1 else {}),
                        **({"rehearsal": "MC_BENCH_BACKEND=gloo: ranks share GPUs, gather staged through the host; "
@@ -322,22 +368,20 @@ def main():
                        **({"verified_equal_to_single_gpu": verified} if verified is not None else {})},
             "roofline": {"bound": "valu", "kernel": kern, "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_TFLOPS,
+                         # the same algorithmic rate against the FMA-counted peak at the clock this box actually held
+                         "frac_at_measured_clock": achieved_tflops * 1e12 / (2.0 * peak_at_clock),
+                         # executed fp32 lane-flops (committed PMC instruction mix) over the live kernel time
+                         "executed": (exec_flops / (kernel_ms * 1e-3) / 1e12) if exec_flops else None,
+                         "executed_frac": (exec_flops / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS) if exec_flops else None,
+                         "executed_source": exec_source,
                          "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_ratio": (traffic / alg_bytes) if traffic else None,
                          "kernel_ms": kernel_ms, "flops_per_unit": flops_per_unit,
-                         # HBM is not the bound: the algorithmic bytes are the 16-B storage-buffer entry per pixel
-                         # (+4 B iteration count for Mandelbrot), written once per launch
                          "hbm": {"algorithmic_bytes": alg_bytes, "gbps": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak_gbps": 8000.0},
                          "lane_ops": {"achieved": achieved_tflops * 1e12, "peak": PEAK_LANE_OPS,
                                       "frac": achieved_tflops * 1e12 / PEAK_LANE_OPS,
-                                      # the same against the lane-op rate at the clock this box actually holds under load
-                                      "frac_at_measured_clock": achieved_tflops * 1e12 / (cus * 4 * 32 * sclk_mhz * 1e6),
-                                      "note": ("142 = the reference composition's literal flop count; the kernel gets the same "
-                                               "bits from ~87 issued instructions (Dekker error term = one fma, exact), "
-                                               "so this fraction may exceed 1") if (not is_pt and cfg["ds"]) else
-                                              ("fast math: hardware transcendentals, a*b+c contraction, identities of exact arithmetic not executed "
-                                               "(toleranced parity; the algorithmic flop count is the reference's, not the executed one); "
-                                               "the strict kernel, reported beside it, forbids all three") if is_pt and args.math == "fast"
-                                              else "parity forbids contraction: one issue slot per flop"}},
+                                      "frac_at_measured_clock": achieved_tflops * 1e12 / peak_at_clock,
+                                      "note": note}},
         }
 
     # ---- secondary metric + strict-math leg: rank 0, N = 1, default headline only, outside the timed region ----------

@@ -12,6 +12,7 @@ import __graft_entry__ as entry  # noqa: E402
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "diag: diagnostic builds kept for the record (rejected kernels); skipped unless MC_RUN_DIAG=1")
 
 
 @pytest.fixture(scope="session")

@@ -72,3 +72,9 @@ def test_clock_probe_reports_a_plausible_shader_clock(ctx):
     assert 1200.0 < mhz < 2500.0, mhz
     again = ctx.measure_clock()
     assert abs(again - mhz) / mhz < 0.08
+
+
+def test_shipped_library_refuses_the_regroup_flag(ctx, B):
+    with pytest.raises(B.McError) as e:
+        ctx.pathtrace(B.pathtrace_params(8, 8, 4, flags=B.PT_KERNEL_REGROUP))
+    assert e.value.status == 5    # MC_ERR_UNSUPPORTED

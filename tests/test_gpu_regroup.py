@@ -1,6 +1,6 @@
 """Parity of the lane-regrouping path tracer kernel (csrc/pathtrace_regroup.h).  The kernel is NOT part of the shipped
 library — it measured slower than the round-synchronous kernels — and lives in the diagnostic library
-lib/libmc_compute_regroup.so (`make regroup`, built by __graft_entry__.build()).  Its scheduling moves paths between
+lib/libmc_compute_regroup.so (`make regroup`; built on demand by this module, NOT by __graft_entry__.build()).  Its scheduling moves paths between
 lanes and waves and finishes samples out of order, so bit-identity with the oracle is the meaningful test: strict math,
 every size / depth / range / tile case below must match bit for bit.  Each case runs in a child process that loads the
 diagnostic library through MC_LIB_PATH (the parent's library stays the shipped one)."""
@@ -12,7 +12,9 @@ import pytest
 
 from conftest import ROOT
 
-pytestmark = pytest.mark.gpu
+# A documented negative result is not part of the driver's `-m gpu` run: marker `diag`, opt in with MC_RUN_DIAG=1 on a GPU box.
+pytestmark = [pytest.mark.diag,
+              pytest.mark.skipif(not os.environ.get("MC_RUN_DIAG"), reason="diagnostic kernel: set MC_RUN_DIAG=1 on a GPU box")]
 
 LIB = os.path.join(ROOT, "vulkan-compute-tests_amd", "lib", "libmc_compute_regroup.so")
 
@@ -69,14 +71,7 @@ print("REGROUP PARITY OK")
 
 
 def test_regroup_kernel_bit_exact_in_the_diagnostic_library(B):
-    if not os.path.exists(LIB):
-        pytest.skip("lib/libmc_compute_regroup.so not built (make -C vulkan-compute-tests_amd regroup)")
+    subprocess.check_call(["make", "-s", "-j", "8", "-C", os.path.join(ROOT, "vulkan-compute-tests_amd"), "regroup"])
     r = subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, MC_LIB_PATH=LIB), capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "REGROUP PARITY OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
-
-
-def test_shipped_library_refuses_the_regroup_flag(ctx, B):
-    with pytest.raises(B.McError) as e:
-        ctx.pathtrace(B.pathtrace_params(8, 8, 4, flags=B.PT_KERNEL_REGROUP))
-    assert e.value.status == 5    # MC_ERR_UNSUPPORTED
