@@ -107,12 +107,16 @@ enum {
     MC_PT_MATH_FAST = 1    /* gfx950 hardware rcp/rsq/sqrt/sin/cos/exp/log: toleranced parity    */
 };
 
-/* mc_pathtrace_params.flags — diagnostics; every combination produces bit-identical buffers */
+/* mc_pathtrace_params.flags — diagnostics.  In MC_PT_MATH_STRICT every accepted combination produces bit-identical buffers;
+ * in MC_PT_MATH_FAST the kernels selected by different flags are different instruction sequences that agree within the
+ * fast-math tolerance, and only the sample-parallel widths of ONE kernel are bit-identical to each other. */
 enum {
     MC_PT_GENERIC_KERNEL = 1u << 0, /* never use the axis-aligned-slab specialisation of the plane test */
-    MC_PT_KERNEL_REGROUP = 1u << 1  /* DIAGNOSTIC library only (make regroup -> lib/libmc_compute_regroup.so): the lane-     */
+    MC_PT_KERNEL_REGROUP = 1u << 1, /* DIAGNOSTIC library only (make regroup -> lib/libmc_compute_regroup.so): the lane-     */
                                     /* regrouping scheduler (csrc/pathtrace_regroup.h), measured slower than the default     */
                                     /* kernels; the shipped library returns MC_ERR_UNSUPPORTED for this flag      */
+    MC_PT_NO_BOX_KERNEL = 1u << 2   /* fast math: never use the closed-box specialisations (compile-time scene facts, the     */
+                                    /* sample-pool kernel); the general fast slab kernel runs instead (A/B measurements)      */
 };
 #define MC_PT_FORCE_S(s) ((uint32_t)(s) << 8) /* force the sample-parallel width: 1, 4 or 16 (0 = automatic) */
 /* Sphere-test precision branch of pathTracer.comp:132-256.  The reference compiles every variant OUT

@@ -159,10 +159,23 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
             a.cam_occ[i] = (ox * ox + oy * oy) + oz * oz;
         }
         a.scene.materials_known = 1u;
+        bool glass_wall = false;
         for (uint32_t i = 0; i < n_planes + n_spheres; i++) {
             const float m = floorf(a.scene.obj[12 * i + 11] + 0.5f);          // the kernel's int(floor(m + 0.5)), :378/:384
             if (!(m == 1.0f || m == 2.0f || m == 3.0f)) a.scene.materials_known = 0u;
+            if (i < n_planes && m == 3.0f) glass_wall = true;
         }
+        // accmat stays finite — so that `accmat * e` of a non-emitting object IS a zero and :391's add can be skipped — when every
+        // colour component is finite and in [0, 1] (accmat * c, accmat / max(c) <= 1 per step; the glass weights Re/P, Tr/(1-P)
+        // are < 4/3) and the depth limit is small enough for 4/3 per bounce to stay far from overflow.
+        a.scene.emit_skip_ok = p->max_depth <= 64u ? 1u : 0u;
+        for (uint32_t i = 0; i < n_planes + n_spheres; i++)
+            for (int k = 8; k < 11; k++) {
+                const float c = a.scene.obj[12 * i + k];
+                if (!(c >= 0.0f && c <= 1.0f)) a.scene.emit_skip_ok = 0u;     // also rejects NaN
+            }
+        // closed-box fast kernel: no ray may ever leave the box (pathtrace_kernel.h, intersect_box)
+        a.scene.box_ok = (a.scene.nee_skip_planes && a.scene.materials_known && !glass_wall && a.scene.emit_skip_ok) ? 1u : 0u;
     } else {      // any other scene: device buffer [records | emissive sphere indices], staged into LDS by the kernel
         std::vector<float> host((size_t)(n_planes + n_spheres) * 12 + n_spheres);
         if (n_planes) std::memcpy(host.data(), planes, sizeof(float) * 12 * n_planes);
@@ -181,10 +194,10 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
             int rc = ctx->drain_launch_streams();
             if (rc) return rc;
             if ((rc = ctx->scene_buf.reserve(host.size() * sizeof(float) + 16))) return rc;
-            ctx->scene_host = host;   // the async copy below reads ctx->scene_host, which outlives it
-            MC_HIP_TRY(hipMemcpyAsync(ctx->scene_buf.ptr, ctx->scene_host.data(), host.size() * sizeof(float),
-                                      hipMemcpyHostToDevice, s));
-            MC_HIP_TRY(hipStreamSynchronize(s));   // pageable source: the copy is staged before the call returns anyway
+            ctx->scene_host.clear();   // the cache key is only valid once the upload has succeeded
+            MC_HIP_TRY(hipMemcpyAsync(ctx->scene_buf.ptr, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, s));
+            MC_HIP_TRY(hipStreamSynchronize(s));   // pageable source `host` (a local): staged before the call returns
+            ctx->scene_host = std::move(host);
         }
         a.scene.d_obj = (const float*)ctx->scene_buf.ptr;
         a.scene.d_emissive = (const uint32_t*)((const float*)ctx->scene_buf.ptr + (size_t)(n_planes + n_spheres) * 12);
@@ -196,6 +209,7 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
     if (S != 1 && S != 4 && S != 16) return MC_ERR_INVALID_ARGUMENT;
     if (prec != 0 && S == 4) S = (p->sample_end - p->sample_begin) >= 16 ? 16 : 1;   // precision variants exist for S = 1, 16
     int variant = slab ? 1 : 0;
+    if (slab && p->math_mode == MC_PT_MATH_FAST && a.scene.box_ok && !(p->flags & MC_PT_NO_BOX_KERNEL)) variant = 3;
     // Lane-regrouping scheduler (pathtrace_regroup.h): slab scenes whose materials are all 1..3 (any other code makes the
     // shader re-trace an unchanged ray, which only the round-synchronous loop reproduces) within its packed-field limits.
     bool regroup_ok = slab && prec == 0 && p->max_depth <= 63u && p->width < 65536u && p->height <= 65536u &&

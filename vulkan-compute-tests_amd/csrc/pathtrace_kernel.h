@@ -59,6 +59,12 @@ struct SceneArgs {
     // Slab kernels: non-zero when every object's material code int(floor(m + 0.5)) is 1, 2 or 3, i.e. every bounce continues
     // from its hit point.  Any other code leaves the ray untouched (:400-448 match nothing) and the same ray is traced again.
     uint32_t materials_known;
+    // Slab kernels: non-zero when the host proved that accmat stays finite (every colour component finite and in [0, 1], depth
+    // limit small): only then is `accmat * e` of a non-emitting object a zero and the emission add skippable (see :391 below)
+    uint32_t emit_skip_ok;
+    // Fast math only: non-zero when the scene may take the closed-box kernel (Box = true): nee_skip_planes (closed box, camera
+    // and lights inside), every material known, no wall of glass — no ray ever leaves the box, so every plane parameter is >= 0
+    uint32_t box_ok;
     float obj[(kMaxPlanes + kMaxSpheres) * 12];
     float r2[kMaxSpheres];
     // slab form of axis-aligned planes (valid only for the Slab kernels): per axis the plane whose normal
@@ -72,6 +78,7 @@ struct SceneArgs {
     const uint32_t* d_emissive;
     uint32_t n_emissive;
     uint32_t pad2;
+    uint32_t pad3, pad4;
 };
 
 struct PTArgs {
@@ -209,6 +216,32 @@ static __device__ unsigned long long g_region_lanes[16];
 #define MC_TIME_MARK(r) do { } while (0)
 #define MC_TIME_COUNT(r, v) do { } while (0)
 #define MC_TIME_FLUSH do { } while (0)
+#endif
+
+// Diagnostic build only (make wavetime -> lib/libmc_compute_wavetime.so, tools/pt_wave_time.py): shader cycles a wave spends between
+// consecutive marks of the bounce loop, summed per region in LDS and flushed once per block — where the TIME of an iteration
+// goes, as opposed to where its instructions are (the two differ: issue classes, EXEC-empty instructions, dependency stalls).
+// A mark attributes the cycles since the previous mark (of any region) to its region; the first active lane books them.
+#ifdef MC_PT_WAVE_TIME
+static __device__ unsigned long long g_wave_time[32];
+static __device__ unsigned long long g_wave_marks[32];
+// (the time of the wave's previous mark lives in LDS, one word per wave: a C variable assigned inside divergent control flow
+// would become a per-lane value, and a lane that left the loop early would book the iterations it sat out)
+struct WaveTime { unsigned int* lds; unsigned int slot; };
+#define MC_WT(r)                                                                                \
+    do {                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        const unsigned int n_ = (unsigned int)__builtin_amdgcn_s_memtime();                     \
+        const unsigned long long m_ = __ballot(1);                                              \
+        if ((int)__lane_id() == __ffsll((long long)m_) - 1) {                                   \
+            atomicAdd(&wt.lds[r], n_ - wt.lds[wt.slot]); atomicAdd(&wt.lds[32 + (r)], 1u);      \
+            wt.lds[wt.slot] = (unsigned int)__builtin_amdgcn_s_memtime();                       \
+        }                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    } while (0)
+#else
+struct WaveTime {};
+#define MC_WT(r) do { } while (0)
 #endif
 
 // Fast mode only: MC_PT_FAST_CONTRACT selects where the compiler may contract a*b+c (pathtrace_fast.hip):
@@ -387,6 +420,17 @@ __device__ __forceinline__ bool shadow_reaches_sphere(const HotSlab& h, v3 o, v3
     return !(dd[1] < dd[0]) && !(dd[2] < dd[0]) && dd[0] < h.inf;
 }
 
+// ---- closed-box kernels (fast math only, Box = true) ---------------------------------------------------------------------
+// The host proved (SceneArgs::box_ok: closed box, camera and lights inside with a margin, every material 1..3, no wall of
+// glass, colours in [0, 1]) what the general slab kernel tests at run time: materials_known, nee_skip_planes and emit_skip_ok
+// are compile-time truths here, which removes their selects and one copy of the shadow-ray code (K2 19.37 -> 19.10 ms).
+// (Round 3 also tried a branch-free "packed minimum" intersection for these kernels — candidates t - eps as unsigned bit
+// patterns with the object id in the low mantissa bits, one v_min3_u32 tree, square roots taken unconditionally.  4 % fewer
+// instructions, yet 20.1-21.0 ms and outside the tolerance (id bits in t: rmse 0.27 / p99.9 4.18): gfx950 issues every
+// non-transcendental VALU instruction in ~2.4 cycles whatever its class, a transcendental blocks the SIMD for 8.2, and the
+// compiler's exec-mask branches skip whole sphere blocks for a wave none of whose lanes can hit — profiles/r03_valu_microbench3.txt,
+// profiles/r03_box_experiment_*.  Removed.)
+
 // intersect — pathTracer.comp:112-131 + :316-341.  Returns the hit object id (planes 0..NP-1, spheres
 // NP..NP+NS-1) or -1, and the ray parameter.  NP/NS < 0 select run-time counts; `obj` is the record array the
 // loops read with wave-uniform indices: the kernel-argument copy (SGPR operands) for the specialised kernels,
@@ -485,11 +529,11 @@ __device__ __forceinline__ void stage_records(float* lds_obj, const float* __res
     __syncthreads();
 }
 
-// One sample: returns accrad (pathTracer.comp:356-449).
-template <bool Fast, int NP, int NS, bool Slab, int Prec>
+// One sample: returns accrad (pathTracer.comp:356-449).  Box (fast math, slab scenes with SceneArgs::box_ok): see above.
+template <bool Fast, int NP, int NS, bool Slab, int Prec, bool Box = false>
 __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restrict__ lds_obj,
                                            const uint32_t* __restrict__ lds_emissive, const HotSlab& hot, uint32_t gx, uint32_t gy,
-                                           uint32_t samp) {
+                                           uint32_t samp, WaveTime& wt) {
     const SceneArgs& sc = a.scene;
     constexpr bool LdsScene = NP < 0;
     const float* __restrict__ uobj = LdsScene ? lds_obj : sc.obj;   // records read with wave-uniform indices
@@ -518,6 +562,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
     float occ[3] = {0.0f, 0.0f, 0.0f};
     float t = 0.0f;
     int id = -1;
+    static_assert(!Box || (Fast && Slab), "the closed-box specialisation is a fast-math slab kernel");
     MC_REGION(0);   // ray generation done
     if constexpr (Slab) {
         MC_REGION(1);   // primary intersect (camera ray)
@@ -526,6 +571,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
         for (int i = 0; i < 3; i++) { oc0[i] = v3{a.cam_oc[i][0], a.cam_oc[i][1], a.cam_oc[i][2]}; occ[i] = a.cam_occ[i]; }
         if (a.max_depth != 0u) id = intersect_slab<Fast>(hot, ro, rd, t, false, occ, oc0);
     }
+    MC_WT(7);   // ray generation + the camera ray's intersection
     for (uint32_t depth = 0; depth < a.max_depth; depth++) {              // :367
         if constexpr (!Slab) {
             MC_REGION(1);   // primary intersect
@@ -563,7 +609,8 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
         // :391 accrad += accmat * e * emissive.  For an object without emission (e = +-0) the product is a zero and
         // accrad (never -0: it starts at +0 and only receives sums) is unchanged, so the nine operations are skipped when no
         // lane of the wave hit an emitter — almost always (slab kernels; the flag sits in the record's unused slot 3).
-        if (!Slab || __ballot(obj[3] != 0.0f) != 0ull) {
+        // (the host proves the premise — accmat finite: colours in [0, 1], emit_skip_ok — else inf * 0 = NaN must be formed)
+        if (!Slab || !(Box || sc.emit_skip_ok) || __ballot(obj[3] != 0.0f) != 0ull) {
             v3 emi{obj[4], obj[5], obj[6]};
             accrad = accrad + (accmat * emi) * emissive;
         }
@@ -575,7 +622,8 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
         }
         // every material 1..3 continues from x (:429,:434,:447): with all materials known (uniform) the assignment is made once,
         // ahead of the dispatch, so that no branch has to copy it at the merge
-        if constexpr (Slab) { if (sc.materials_known) ro = x; }
+        if constexpr (Slab) { if (Box || sc.materials_known) ro = x; }
+        MC_WT(0);   // prologue: hit point, c - x, record fetch, normal, emission, rand01, Russian roulette
         if (mat == 1) {                                                   // :400 diffuse
             MC_REGION(3);   // diffuse: NEE set-up + shadow ray
             const int n_lights = LdsScene ? (int)sc.n_emissive : ns;
@@ -612,13 +660,15 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 v3 l = Fast ? (su * (cphi * sin_a) + sv * (sphi * sin_a)) + sw * cos_a
                             : normalize_unit_combination<Fast, true>(((su * cphi) * sin_a + (sv * sphi) * sin_a) + sw * cos_a);   // :413
                 float tne;
+                MC_WT(1);   // light sample: cone, basis, direction
                 bool reached;                                             // :420 shadow ray: is the nearest hit sphere i?
                 if constexpr (Slab) {
-                    if (sc.nee_skip_planes != 0u) reached = shadow_reaches_sphere<Fast>(hot, x, l, i, xc, occ);
+                    if (Box || sc.nee_skip_planes != 0u) reached = shadow_reaches_sphere<Fast>(hot, x, l, i, xc, occ);
                     else reached = intersect_slab<Fast>(hot, x, l, tne, false) == np + i;
                 } else {
                     reached = intersect<Fast, NP, NS, Slab, Prec>(sc, uobj, x, l, tne, false) == np + i;
                 }
+                MC_WT(2);   // shadow ray
                 if (reached) {
                     MC_REGION(4);   // shadow ray reached the light
                     float omega = (2.0f * kPi) * (1.0f - cos_a_max);      // :421
@@ -630,6 +680,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                     }
                 }
             }
+            MC_WT(3);   // light contribution
             MC_REGION(8);   // diffuse bounce direction
             float r1 = (2.0f * kPi) * rnd.x, r2 = rnd.y, r2s = dm::fsqrt<Fast>(r2);   // :426
             v3 w = nl;
@@ -641,8 +692,9 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             // plane normal is used as given, and there :428's normalize is not an identity)
             rd = Fast ? normalize_unit_combination<Fast, Slab>((u * (c1 * r2s) + v * (s1 * r2s)) + w * dm::fsqrt<Fast>(1.0f - r2))
                       : normalize_unit_combination<Fast, Slab>(((u * c1) * r2s + (v * s1) * r2s) + w * dm::fsqrt<Fast>(1.0f - r2));   // :428
-            if (!Slab || !sc.materials_known) ro = x;   // (slab scenes of known materials: moved ahead of the dispatch)
+            if (!Slab || (!Box && !sc.materials_known)) ro = x;   // (slab scenes of known materials: moved ahead of the dispatch)
             emissive = 0.0f;                                              // :429
+            MC_WT(4);   // diffuse bounce direction
         } else if (mat == 2 || mat == 3) {                                // :432 mirror, :437 glass
             // one block for both specular materials: the glass branch needs reflect(rd, n) (:444, :446) — the mirror's whole
             // bounce (:433) — so a wave that holds lanes of both kinds evaluates it once
@@ -707,18 +759,20 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 rd = refl;                                                    // :433
             }
             }   // (general form)
-            if (!Slab || !sc.materials_known) ro = x;   // (slab scenes of known materials: moved ahead of the dispatch)
+            if (!Slab || (!Box && !sc.materials_known)) ro = x;   // (slab scenes of known materials: moved ahead of the dispatch)
             emissive = 1.0f;                                              // :447
+            MC_WT(5);   // mirror / glass
         }
         if constexpr (Slab) {
             if (depth + 1u < a.max_depth) {                               // (uniform) the intersection of the next depth
                 MC_REGION(1);
-                if (!sc.materials_known) {   // (uniform, cold) an unknown material kept its ray: c_i - o must follow ro, not x
+                if (!Box && !sc.materials_known) {   // (uniform, cold) an unknown material kept its ray: c_i - o must follow ro, not x
 #pragma unroll
                     for (int i = 0; i < 3; i++) { xoc[i] = v3{hot.c[i][0], hot.c[i][1], hot.c[i][2]} - ro; occ[i] = dot(xoc[i], xoc[i]); }
                 }
                 id = intersect_slab<Fast>(hot, ro, rd, t, false, occ, xoc);
             }
+            MC_WT(6);   // intersection of the next depth
         }
     }
     return accrad;
@@ -735,7 +789,7 @@ template <> struct WaveTile<64> { static constexpr uint32_t w = 1, h = 1; };
 template <int S> constexpr uint32_t block_w() { return 2u * WaveTile<S>::w; }
 template <int S> constexpr uint32_t block_h() { return 2u * WaveTile<S>::h; }
 
-template <bool Fast, int NP, int NS, bool Slab, int S, int Prec>
+template <bool Fast, int NP, int NS, bool Slab, int S, int Prec, bool Box = false>
 __global__ void __launch_bounds__(256, Fast ? 6 : 5) pathtrace_kernel(PTArgs a) {
     // dynamic LDS (no static __shared__ in front: the base stays 16-B aligned): [records | emissive list]
     extern __shared__ float lds_dyn[];
@@ -771,6 +825,15 @@ __global__ void __launch_bounds__(256, Fast ? 6 : 5) pathtrace_kernel(PTArgs a) 
         c.idx = c.valid ? (size_t)ty * a.W + c.gx : 0;
         return c;
     };
+    WaveTime wt;
+#ifdef MC_PT_WAVE_TIME
+    __shared__ unsigned int lds_wave_time[72];
+    if (threadIdx.x < 64u) lds_wave_time[threadIdx.x] = 0u;
+    __syncthreads();
+    wt.lds = lds_wave_time;
+    wt.slot = 64u + (threadIdx.x >> 6);
+    if ((threadIdx.x & 63u) == 0u) lds_wave_time[wt.slot] = (unsigned int)__builtin_amdgcn_s_memtime();
+#endif
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (a.sample_begin > 0) {   // progressive continuation (samps.x protocol); s==0 resets (:451)
         const LaneCoords c = lane_coords();
@@ -784,9 +847,10 @@ __global__ void __launch_bounds__(256, Fast ? 6 : 5) pathtrace_kernel(PTArgs a) 
         const uint32_t s = base + c.j;
         v3 q{0.0f, 0.0f, 0.0f};
         if (c.valid && s < a.sample_end) {
-            v3 rad = trace_sample<Fast, NP, NS, Slab, Prec>(a, lds_obj, lds_emissive, hot, c.gx, c.gy, s);
+            v3 rad = trace_sample<Fast, NP, NS, Slab, Prec, Box>(a, lds_obj, lds_emissive, hot, c.gx, c.gy, s, wt);
             q = Fast ? rad * a.inv_spp : divs_recip<Fast>(rad, fspp, a.inv_spp);      // :452 accrad / samps.y (inv_spp = RN(1/spp), host)
         }
+        MC_WT(8);   // (idle tail of the round: lanes whose path ended wait for the longest one)
         // fold the round's S samples into the accumulator in sample order (every lane of the group
         // performs the same additions, so all S copies of acc stay identical)
         const uint32_t count = min((uint32_t)S, a.sample_end - base);           // wave-uniform
@@ -805,6 +869,13 @@ __global__ void __launch_bounds__(256, Fast ? 6 : 5) pathtrace_kernel(PTArgs a) 
             }
         }
     }
+#ifdef MC_PT_WAVE_TIME
+    __syncthreads();
+    if (threadIdx.x < 32u) {
+        atomicAdd(&g_wave_time[threadIdx.x], (unsigned long long)lds_wave_time[threadIdx.x]);
+        atomicAdd(&g_wave_marks[threadIdx.x], (unsigned long long)lds_wave_time[32u + threadIdx.x]);
+    }
+#endif
     const LaneCoords c = lane_coords();
     const bool valid = c.valid;
     const uint32_t j = c.j;
@@ -821,7 +892,8 @@ __global__ void __launch_bounds__(256, Fast ? 6 : 5) pathtrace_kernel(PTArgs a) 
 // variant: 0 = generic (run-time object counts), 1 = slab-specialised 6 planes + 3 spheres.
 // prec: 0 = fp32 sphere test (the reference's default build); 1/2/3 = native fp64 / DS / DF64 branch (generic kernel,
 // S in {1,16} only).
-// variant 2 = the lane-regrouping scheduler (pathtrace_regroup.h; slab scenes, S is ignored).
+// variant 2 = the lane-regrouping scheduler (pathtrace_regroup.h; slab scenes, S is ignored; diagnostic library only).
+// variant 3 = the closed-box fast kernel (slab scenes with SceneArgs::box_ok, fast math only).
 int launch_fast(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s);
 int launch_strict(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s);
 
@@ -830,14 +902,14 @@ inline size_t scene_lds_bytes(const PTArgs& a) {
 }
 constexpr size_t kMaxSceneLdsBytes = 144u * 1024u;   // of the 160 KB per CU: 3072 objects
 
-template <bool Fast, int NP, int NS, bool Slab, int S, int Prec>
+template <bool Fast, int NP, int NS, bool Slab, int S, int Prec, bool Box = false>
 inline int launch_one(const PTArgs& a, uint32_t tile_rows, hipStream_t s) {
     dim3 grid((a.W + block_w<S>() - 1u) / block_w<S>(), (tile_rows + block_h<S>() - 1u) / block_h<S>());
     size_t lds = scene_lds_bytes(a);
 #ifdef MC_PT_DIAG_LDS_PAD   // diagnostic build only (make variants): pad the dynamic LDS to cap the resident waves per CU
     if (const char* e = std::getenv("MC_PT_LDS_PAD")) lds += (size_t)std::atoi(e);
 #endif
-    auto kern = pathtrace_kernel<Fast, NP, NS, Slab, S, Prec>;
+    auto kern = pathtrace_kernel<Fast, NP, NS, Slab, S, Prec, Box>;
     if (lds > 48u * 1024u) {   // beyond the default dynamic-LDS window: opt in (gfx950 has 160 KB per CU)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
@@ -852,6 +924,15 @@ inline int launch_one(const PTArgs& a, uint32_t tile_rows, hipStream_t s) {
 template <bool Fast>
 inline int launch_impl(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s) {
     if (prec == 0) {
+        if constexpr (Fast) {
+            if (variant == 3) {
+                if (S == 1) return launch_one<Fast, 6, 3, true, 1, 0, true>(a, tile_rows, s);
+                if (S == 4) return launch_one<Fast, 6, 3, true, 4, 0, true>(a, tile_rows, s);
+                if (S == 16) return launch_one<Fast, 6, 3, true, 16, 0, true>(a, tile_rows, s);
+                return MC_ERR_INVALID_ARGUMENT;
+            }
+        }
+        if (variant == 3) return MC_ERR_INVALID_ARGUMENT;
         if (variant == 1) {
             if (S == 1) return launch_one<Fast, 6, 3, true, 1, 0>(a, tile_rows, s);
             if (S == 4) return launch_one<Fast, 6, 3, true, 4, 0>(a, tile_rows, s);
