@@ -47,6 +47,8 @@ struct Cost {
     double commit_item = 1.5; // regroup kernel: ordered commit, per item
 };
 
+static Cost g_cost;
+
 struct Path {
     const uint8_t* ev;   // events: per bounce 0 = RR-terminated after intersect+prologue, 1/2/3 = material executed
     int n;               // number of hits recorded (a miss ends the list early)
@@ -429,15 +431,72 @@ void sim_sorted_rounds(const Tile& t, int pixels, int spp, int max_depth, const 
 
 }  // namespace
 
+
+// ---------------------------------------------------------------- sample-pool kernel (round 3)
+// One wave owns P = 64/S pixels and ALL their samples as one pool in batch order (batch b = samples b*S .. b*S+S-1 of every
+// pixel).  Camera rays (+ their first intersection) are generated 64 at a time at full width into a stash; a lane whose path
+// ended pops the next stash entry at the top of the next iteration — of any pixel of the wave.  No exchange of path state
+// between lanes, no ordered commit (radiance goes to per-pixel LDS accumulators as it arises: fast math only).
+// Cost per iteration: the blocks that have a lane (as `rounds`) + ov_pop when a lane pops + ov_lane (per-lane depth tests that
+// were scalar in the round-synchronous kernel); per batch: cam + first intersection.
+struct PoolCfg { int S = 16; double ov_pop = 16, ov_lane = 7, batch = 150; int pop_every = 1; };
+void sim_pool(const Tile& t, int pix0, int spp, int max_depth, const Cost& c, const PoolCfg& g, Stats& st) {
+    const int P = 64 / g.S;
+    const int batches = (spp + g.S - 1) / g.S;
+    long generated = 0, popped = 0;          // entries; entry e -> batch e / 64, pixel (e % 64) / S, sample batch * S + e % S
+    const long total = (long)batches * 64;
+    const std::vector<uint8_t>* ev[64];
+    int pos[64], alive[64];
+    for (int l = 0; l < 64; l++) { alive[l] = 0; ev[l] = nullptr; pos[l] = 0; }
+    long iter = 0;
+    for (;;) {
+        int dead = 0;
+        for (int l = 0; l < 64; l++) dead += !alive[l];
+        bool pop_now = dead > 0 && (iter % g.pop_every == 0 || dead == 64);
+        if (pop_now) {
+            if (generated - popped < dead && generated < total) { generated += 64; st.cost += g.batch; st.useful += g.batch; }
+            bool any = false;
+            for (int l = 0; l < 64 && popped < generated; l++) {
+                if (alive[l]) continue;
+                long e = popped++;
+                int b = (int)(e / 64), p = (int)(e % 64) / g.S, s = b * g.S + (int)(e % g.S);
+                if (s >= spp) continue;       // ragged last batch: entry dropped at generation (compacted)
+                ev[l] = &t.samples[(size_t)(pix0 + p) * spp + s]; pos[l] = 0; alive[l] = 1; any = true;
+                st.n_samples++;
+            }
+            if (any) { st.cost += g.ov_pop; }
+        }
+        int na = 0, nd = 0, ng = 0, nm = 0;
+        for (int l = 0; l < 64; l++) {
+            if (!alive[l]) continue;
+            na++;
+            if (pos[l] >= (int)ev[l]->size() || pos[l] >= max_depth) { alive[l] = 0; continue; }
+            int e = (*ev[l])[pos[l]++];
+            if (e == 0) alive[l] = 0;
+            else if (e == 1) nd++;
+            else if (e == 2) nm++;
+            else ng++;
+            if (pos[l] >= max_depth) alive[l] = 0;   // depth limit: ends after its material block
+        }
+        if (!na) { if (popped >= total) break; iter++; continue; }
+        st.iters += 1;
+        st.cost += c.ip + g.ov_lane + (nd ? c.d : 0) + (ng ? c.g : 0) + (nm ? c.m : 0);
+        st.useful += (na * c.ip + nd * c.d + ng * c.g + nm * c.m) / 64.0;
+        iter++;
+    }
+}
+
 int main(int argc, char** argv) {
     int W = 900, H = 600, spp = 500, max_depth = 12, n_tiles = 32, pixels = 64;
-    bool only_streams = false;
+    bool only_streams = false, only_pool = false;
     unsigned seed = 1;
     for (int i = 1; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--spp")) spp = atoi(argv[i + 1]);
         if (!strcmp(argv[i], "--tiles")) n_tiles = atoi(argv[i + 1]);
         if (!strcmp(argv[i], "--seed")) seed = atoi(argv[i + 1]);
-        if (!strcmp(argv[i], "--only")) only_streams = !strcmp(argv[i + 1], "streams");
+        if (!strcmp(argv[i], "--only")) { only_streams = !strcmp(argv[i + 1], "streams"); only_pool = !strcmp(argv[i + 1], "pool"); }
+        if (!strcmp(argv[i], "--cost")) { /* current kernel (r03 PMC: 3943 wave-instructions per round): ip d g m cam */
+            sscanf(argv[i + 1], "%lf,%lf,%lf,%lf,%lf", &g_cost.ip, &g_cost.d, &g_cost.g, &g_cost.m, &g_cost.cam); }
     }
     oracle::PT<TracePolicy> pt;
     pt.planes = kPlanes; pt.nPlanes = 6; pt.spheres = kSpheres; pt.nSpheres = 3; pt.mathMode = oracle::MATH_LIBM;
@@ -464,11 +523,21 @@ int main(int argc, char** argv) {
     }
     printf("traced %d tiles x %d pixels x %d spp: %.2f hits/sample; events: RR-terminated %.3f diffuse %.3f mirror %.3f glass %.3f\n",
            n_tiles, pixels, spp, bounces / nsamp, hist[0] / bounces, hist[1] / bounces, hist[2] / bounces, hist[3] / bounces);
-    Cost c;
+    Cost c = g_cost;
     Stats base;
     for (auto& t : tiles) sim_rounds(t, pixels, spp, max_depth, c, base);
     printf("%-58s cost/sample %7.1f  lanes %.3f  iters/64samples %.2f\n", "rounds (round 1 kernel)", base.cost / base.n_samples,
            base.useful / base.cost, base.iters * 64.0 / base.n_samples);
+    for (int S : {16, 4, 1})
+        for (double ovp : {16.0, 30.0, 45.0})
+            for (int every : {1, 2}) {
+                PoolCfg g; g.S = S; g.ov_pop = ovp; g.pop_every = every;
+                Stats s;
+                for (auto& t : tiles) for (int p0 = 0; p0 + 64 / S <= pixels; p0 += 64 / S) sim_pool(t, p0, spp, max_depth, c, g, s);
+                printf("pool S=%2d pop overhead %2.0f every %d iteration(s) : cost/sample %7.1f (%.3fx)  lanes %.3f  iters/64samples %.2f\n", S, ovp, every,
+                       s.cost / s.n_samples, (base.cost / base.n_samples) / (s.cost / s.n_samples), s.useful / s.cost, s.iters * 64.0 / s.n_samples);
+            }
+    if (only_pool) return 0;
     for (int S : {1, 4, 16})
         for (int la : {1, 2, 3, 4, 6, 8, 1 << 30})
             for (int stash : {2, 4}) {

@@ -251,6 +251,9 @@ struct WaveTime {};
 #ifndef MC_PT_DECISION_FP
 #define MC_PT_DECISION_FP
 #endif
+#ifndef MC_PT_FAST_PLANES_ONE_RCP   // fast math: one division for the three slab tests (intersect_slab)
+#define MC_PT_FAST_PLANES_ONE_RCP 1
+#endif
 
 constexpr float kEps = 1e-4f, kTriEps = 1e-7f, kInf = 1e20f;   // pathTracer.comp:103-105
 constexpr float kPi = 3.141592653589793f;                       // :102
@@ -358,7 +361,31 @@ __device__ __forceinline__ int intersect_slab(const HotSlab& h, v3 o, v3 d, floa
     MC_PT_DECISION_FP
     float t = h.inf;
     int id = -1;
-    if (!shadow_skip_planes) {
+    if (Fast && MC_PT_FAST_PLANES_ONE_RCP && !shadow_skip_planes) {
+        // Fast math: the nearest of the three facing planes is found BEFORE dividing — (W_a - o_a) / d_a < (W_b - o_b) / d_b is
+        // compared as |W_a - o_a| |d_b| < |W_b - o_b| |d_a| (numerator and denominator of a facing plane have the same sign) —
+        // and only the winner is divided: one v_rcp_f32 (8 issue cycles, profiles/r03_valu_microbench3.txt) instead of three,
+        // and t is the same product the three-division form computes for that plane.  A plane the ray runs parallel to
+        // (|d_a| <= 1e-7, :119) loses every comparison against a real candidate; decisions differ from the reference's only
+        // at ties of two planes' parameters (the edges of the box).
+        float num[3], den[3];
+        int pid[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float da = comp(d, a), oa = comp(o, a);
+            const bool pos = da > 0.0f;
+            num[a] = (pos ? h.W_pos[a] : h.W_negm[a]) - oa; den[a] = da; pid[a] = pos ? 2 * a + 1 : 2 * a;
+        }
+        float bn = num[0], bd = den[0];
+        int bid = pid[0];
+#pragma unroll
+        for (int a = 1; a < 3; a++) {
+            const bool nearer = __builtin_fabsf(num[a]) * __builtin_fabsf(bd) < __builtin_fabsf(bn) * __builtin_fabsf(den[a]);
+            bn = nearer ? num[a] : bn; bd = nearer ? den[a] : bd; bid = nearer ? pid[a] : bid;
+        }
+        const float dd = dm::fdiv<Fast>(bn, bd);
+        if (__builtin_fabsf(bd) > h.tri_eps && dd < t) { t = dd; id = bid; }
+    } else if (!shadow_skip_planes) {
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             const float da = comp(d, a), oa = comp(o, a);
@@ -414,7 +441,8 @@ __device__ __forceinline__ bool shadow_reaches_sphere(const HotSlab& h, v3 o, v3
         dd[i] = r;
     }
     // li is a constant of the caller's unrolled light loop
-    if (Fast && li == 2) return dd[2] < __builtin_fminf(dd[0], dd[1]);   // the same test for ordered values (dd <= 1e20)
+    if (Fast && li == 2) return dd[2] < dd[0] && dd[2] < dd[1];   // (dd[k] <= 1e20: the third test is implied; two compares,
+                                                                    // not fminf's two canonicalising v_max + v_min + compare)
     if (li == 2) return dd[2] < dd[0] && dd[2] < dd[1] && dd[2] < h.inf;
     if (li == 1) return dd[1] < dd[0] && !(dd[2] < dd[1]) && dd[1] < h.inf;
     return !(dd[1] < dd[0]) && !(dd[2] < dd[0]) && dd[0] < h.inf;
@@ -529,17 +557,9 @@ __device__ __forceinline__ void stage_records(float* lds_obj, const float* __res
     __syncthreads();
 }
 
-// One sample: returns accrad (pathTracer.comp:356-449).  Box (fast math, slab scenes with SceneArgs::box_ok): see above.
-template <bool Fast, int NP, int NS, bool Slab, int Prec, bool Box = false>
-__device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restrict__ lds_obj,
-                                           const uint32_t* __restrict__ lds_emissive, const HotSlab& hot, uint32_t gx, uint32_t gy,
-                                           uint32_t samp, WaveTime& wt) {
-    const SceneArgs& sc = a.scene;
-    constexpr bool LdsScene = NP < 0;
-    const float* __restrict__ uobj = LdsScene ? lds_obj : sc.obj;   // records read with wave-uniform indices
-    const int np = NP >= 0 ? NP : (int)sc.n_planes;
-    const int ns = NS >= 0 ? NS : (int)sc.n_spheres;
-    // -- sample sensor (:357-362)
+// ---- pieces of one sample shared by the round-synchronous kernels (trace_sample) and the sample-pool kernel (pathtrace_pool.h) --
+// Camera ray through the sensor sample of (pixel, samp) — pathTracer.comp:357-362; returns the direction (the origin is a.lc).
+template <bool Fast> __device__ __forceinline__ v3 camera_ray(const PTArgs& a, uint32_t gx, uint32_t gy, uint32_t samp) {
     v3 r0 = rand01(gx, gy, samp);
     float rnd2x = 2.0f * r0.x, rnd2y = 2.0f * r0.y;
     // :358-:359 tent filter: one sqrt of the selected argument instead of one per branch (the same value either way)
@@ -551,8 +571,76 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
     float sx = ((Fast ? px * a.inv_W : dm::fdiv<Fast>(px, (float)a.W)) - 0.5f) * 0.036f;
     float sy = ((Fast ? py * a.inv_H : dm::fdiv<Fast>(py, (float)a.H)) - 0.5f) * 0.024f;
     v3 spos = (a.cam_o + a.cx * sx) + a.cy * sy;                          // :360
+    return normalize<Fast>(a.lc - spos);                                  // :362
+}
+// Direction towards a point of the light's visible cap (:408-:413): xc = light centre - x, xcc = |xc|^2, lr2 = radius^2.
+template <bool Fast> __device__ __forceinline__ v3 light_sample_direction(v3 xc, float xcc, float lr2, v3 rnd, float& cos_a_max) {
+    const float inv_len = dm::inversesqrt<Fast>(xcc);
+    v3 sw = xc * inv_len;                                     // :409 normalize(xc)
+    v3 su = tangent_u<Fast>(sw);
+    v3 sv = cross(sw, su);
+    // :410; fast: 1 / |xc|^2 is the square of the 1 / |xc| above (one multiply instead of a v_rcp_f32)
+    cos_a_max = dm::fsqrt<Fast>(1.0f - (Fast ? lr2 * (inv_len * inv_len) : dm::fdiv<Fast>(lr2, xcc)));
+    float cos_a = (1.0f - rnd.x) + rnd.x * cos_a_max;         // :411
+    float sin_a = dm::fsqrt<Fast>(1.0f - cos_a * cos_a);
+    float phi = (2.0f * kPi) * rnd.y;                         // :412
+    float sphi, cphi;
+    dm::sincos_angle<Fast>(phi, rnd.y, sphi, cphi);
+    // fast: the two scalar factors of a tangent are multiplied first (u*(c*s) for (u*c)*s: one product less per component)
+    return Fast ? (su * (cphi * sin_a) + sv * (sphi * sin_a)) + sw * cos_a
+                : normalize_unit_combination<Fast, true>(((su * cphi) * sin_a + (sv * sphi) * sin_a) + sw * cos_a);   // :413
+}
+// Cosine-weighted bounce around w = nl (:426-:428).  Unit: w is of unit length (slab kernels: +-1 axis normals, normalised sphere
+// normals); a generic scene's plane normal is used as given, and there :428's normalize is not an identity.
+template <bool Fast, bool Unit> __device__ __forceinline__ v3 cosine_bounce(v3 w, v3 rnd) {
+    float r1 = (2.0f * kPi) * rnd.x, r2 = rnd.y, r2s = dm::fsqrt<Fast>(r2);   // :426
+    v3 u = tangent_u<Fast>(w);                                    // :427
+    v3 v = cross(w, u);
+    float s1, c1;
+    dm::sincos_angle<Fast>(r1, rnd.x, s1, c1);
+    return Fast ? normalize_unit_combination<Fast, Unit>((u * (c1 * r2s) + v * (s1 * r2s)) + w * dm::fsqrt<Fast>(1.0f - r2))
+                : normalize_unit_combination<Fast, Unit>(((u * c1) * r2s + (v * s1) * r2s) + w * dm::fsqrt<Fast>(1.0f - r2));   // :428
+}
+// Mirror / glass bounce in the fast slab form (:432-:447): every outcome is rd*alpha + n*beta — reflection (1, -2 dot(n, rd)),
+// refraction (nnt, -k) — so the scalars are selected and ONE direction is formed; cos of the leaving ray = sqrt(cos2t), c^5
+// through c^2.  mat is 2 or 3; dot_n_rd = dot(n, rd); rx = rnd.x; accmat receives :445's weight.
+__device__ __forceinline__ v3 specular_bounce_fast(int mat, v3 rd, v3 n, float dot_n_rd, float rx, v3& accmat) {
+    MC_PT_DECISION_FP
+    float alpha = 1.0f, beta = -2.0f * dot_n_rd;
+    if (mat == 3) {
+        MC_REGION(6);
+        const bool into = (dm::as_uint(dot_n_rd) >> 31) != 0u;            // :438 (nl == n)
+        const float nnt = into ? 1.0f / 1.5f : 1.5f;                      // :439
+        const float a_dn = __builtin_fabsf(dot_n_rd);                      // = -dot(rd, nl)
+        const float cos2t = 1.0f - (nnt * nnt) * (1.0f - a_dn * a_dn);    // :440
+        if (cos2t >= 0.0f) {
+            MC_REGION(7);
+            const float sq2t = dm::fsqrt<true>(cos2t);
+            const float k = (into ? 1.0f : -1.0f) * (sq2t - a_dn * nnt);  // :441
+            const float c = 1.0f - (into ? a_dn : sq2t), c2 = c * c;
+            const float Re = 0.04f + 0.96f * ((c2 * c2) * c);              // :442-:443, R0 = (0.5/2.5)^2
+            const float P = 0.25f + 0.5f * Re;
+            const bool pick_refl = rx < P;                                // :444
+            accmat = accmat * dm::fdiv<true>(pick_refl ? Re : 1.0f - Re, pick_refl ? P : 1.0f - P);   // :445
+            if (!pick_refl) { alpha = nnt; beta = -k; }
+        }
+    }
+    return rd * alpha + n * beta;
+}
+
+// One sample: returns accrad (pathTracer.comp:356-449).  Box (fast math, slab scenes with SceneArgs::box_ok): see above.
+template <bool Fast, int NP, int NS, bool Slab, int Prec, bool Box = false>
+__device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restrict__ lds_obj,
+                                           const uint32_t* __restrict__ lds_emissive, const HotSlab& hot, uint32_t gx, uint32_t gy,
+                                           uint32_t samp, WaveTime& wt) {
+    const SceneArgs& sc = a.scene;
+    constexpr bool LdsScene = NP < 0;
+    const float* __restrict__ uobj = LdsScene ? lds_obj : sc.obj;   // records read with wave-uniform indices
+    const int np = NP >= 0 ? NP : (int)sc.n_planes;
+    const int ns = NS >= 0 ? NS : (int)sc.n_spheres;
+    // -- sample sensor (:357-362)
     v3 accrad{0.0f, 0.0f, 0.0f}, accmat{1.0f, 1.0f, 1.0f};               // :361
-    v3 ro = a.lc, rd = normalize<Fast>(a.lc - spos);                      // :362
+    v3 ro = a.lc, rd = camera_ray<Fast>(a, gx, gy, samp);                 // :362
     float emissive = 1.0f;                                                // :365
     // slab kernels: |c_i - ro|^2 of the three spheres travels with the ray origin.  Every material continues from the hit
     // point x (:429,:434,:447), where the shadow rays of next-event estimation start too, so the value :318 needs at the next
@@ -645,20 +733,8 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 v3 le{ls[4], ls[5], ls[6]};
                 v3 xc = Slab ? xoc[i] : lc - x;                           // :408
                 const float xcc = Slab ? occ[i] : dot(xc, xc);
-                const float inv_len = dm::inversesqrt<Fast>(xcc);
-                v3 sw = xc * inv_len;                                     // :409 normalize(xc)
-                v3 su = tangent_u<Fast>(sw);
-                v3 sv = cross(sw, su);
-                // :410; fast: 1 / |xc|^2 is the square of the 1 / |xc| above (one multiply instead of a v_rcp_f32)
-                float cos_a_max = dm::fsqrt<Fast>(1.0f - (Fast ? lr2 * (inv_len * inv_len) : dm::fdiv<Fast>(lr2, xcc)));
-                float cos_a = (1.0f - rnd.x) + rnd.x * cos_a_max;         // :411
-                float sin_a = dm::fsqrt<Fast>(1.0f - cos_a * cos_a);
-                float phi = (2.0f * kPi) * rnd.y;                         // :412
-                float sphi, cphi;
-                dm::sincos_angle<Fast>(phi, rnd.y, sphi, cphi);
-                // fast: the two scalar factors of a tangent are multiplied first (u*(c*s) for (u*c)*s: one product less per component)
-                v3 l = Fast ? (su * (cphi * sin_a) + sv * (sphi * sin_a)) + sw * cos_a
-                            : normalize_unit_combination<Fast, true>(((su * cphi) * sin_a + (sv * sphi) * sin_a) + sw * cos_a);   // :413
+                float cos_a_max;
+                v3 l = light_sample_direction<Fast>(xc, xcc, lr2, rnd, cos_a_max);   // :409-:413
                 float tne;
                 MC_WT(1);   // light sample: cone, basis, direction
                 bool reached;                                             // :420 shadow ray: is the nearest hit sphere i?
@@ -682,16 +758,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             }
             MC_WT(3);   // light contribution
             MC_REGION(8);   // diffuse bounce direction
-            float r1 = (2.0f * kPi) * rnd.x, r2 = rnd.y, r2s = dm::fsqrt<Fast>(r2);   // :426
-            v3 w = nl;
-            v3 u = tangent_u<Fast>(w);                                    // :427
-            v3 v = cross(w, u);
-            float s1, c1;
-            dm::sincos_angle<Fast>(r1, rnd.x, s1, c1);
-            // (w = +-n is of unit length in the slab kernels only: +-1 axis normals, normalised sphere normals; a generic scene's
-            // plane normal is used as given, and there :428's normalize is not an identity)
-            rd = Fast ? normalize_unit_combination<Fast, Slab>((u * (c1 * r2s) + v * (s1 * r2s)) + w * dm::fsqrt<Fast>(1.0f - r2))
-                      : normalize_unit_combination<Fast, Slab>(((u * c1) * r2s + (v * s1) * r2s) + w * dm::fsqrt<Fast>(1.0f - r2));   // :428
+            rd = cosine_bounce<Fast, Slab>(nl, rnd);                      // :426-:428
             if (!Slab || (!Box && !sc.materials_known)) ro = x;   // (slab scenes of known materials: moved ahead of the dispatch)
             emissive = 0.0f;                                              // :429
             MC_WT(4);   // diffuse bounce direction
@@ -701,28 +768,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             MC_PT_DECISION_FP
             MC_REGION(5);   // mirror direction = the glass block's reflected direction
             if constexpr (Fast && Slab) {
-                // Fast slab form: every outcome is rd*alpha + n*beta — reflection (1, -2 dot(n, rd)), refraction (nnt, -k) — so
-                // the scalars are selected and ONE direction is formed; cos of the leaving ray = sqrt(cos2t), c^5 through c^2.
-                float alpha = 1.0f, beta = -2.0f * dot_n_rd;
-                if (mat == 3) {
-                    MC_REGION(6);
-                    const bool into = (dm::as_uint(dot_n_rd) >> 31) != 0u;            // :438 (nl == n)
-                    const float nnt = into ? 1.0f / 1.5f : 1.5f;                      // :439
-                    const float a_dn = __builtin_fabsf(dot_n_rd);                      // = -dot(rd, nl)
-                    const float cos2t = 1.0f - (nnt * nnt) * (1.0f - a_dn * a_dn);    // :440
-                    if (cos2t >= 0.0f) {
-                        MC_REGION(7);
-                        const float sq2t = dm::fsqrt<true>(cos2t);
-                        const float k = (into ? 1.0f : -1.0f) * (sq2t - a_dn * nnt);  // :441
-                        const float c = 1.0f - (into ? a_dn : sq2t), c2 = c * c;
-                        const float Re = 0.04f + 0.96f * ((c2 * c2) * c);              // :442-:443, R0 = (0.5/2.5)^2
-                        const float P = 0.25f + 0.5f * Re;
-                        const bool pick_refl = rnd.x < P;                             // :444
-                        accmat = accmat * dm::fdiv<true>(pick_refl ? Re : 1.0f - Re, pick_refl ? P : 1.0f - P);   // :445
-                        if (!pick_refl) { alpha = nnt; beta = -k; }
-                    }
-                }
-                rd = rd * alpha + n * beta;
+                rd = specular_bounce_fast(mat, rd, n, dot_n_rd, rnd.x, accmat);   // (the fast slab form, see there)
             } else {
             const v3 refl = reflect(rd, n);
             if (mat == 3) {

@@ -1,0 +1,226 @@
+// The sample-pool path tracer kernel for gfx950 — fast math, closed-box scenes (SceneArgs::box_ok).  Included by pathtrace_fast.hip.
+//
+// Why: the round-synchronous kernels (pathtrace_kernel.h) step all 64 lanes of a wave through the depths of ONE sample each;
+// Russian roulette (pathTracer.comp:395-397) thins the wave from depth 6 on and the round still costs its longest path, so the
+// intersection + prologue code runs with 52 of 64 lanes and `VALUUtilization` sits at 59 % (profiles/r02_pt_fast_pmc_summary.json).
+// gfx950 issues every VALU instruction in ~2.4 cycles whatever its class or EXEC mask (profiles/r03_valu_microbench3.txt), so
+// what is left is the number of lanes an issued instruction serves.
+//
+// What: a wave owns 64/S pixels; the S lanes of a pixel share ALL its samples as a pool.  Camera rays and their first
+// intersection (:357-362, :316-341) are produced one batch — S consecutive samples of every pixel, 64 rays — at a time at full
+// width into a stash in LDS (two batches deep); a lane whose path ended takes its pixel's next stash entry at the top of the
+// next iteration, so lanes sit at different depths of different samples and the wave stays full until the pool runs dry.
+// No path state ever moves between lanes, there are no queues between waves, no reorder ring: a lane adds the radiance it
+// gathers (:391, :422) to its own register accumulator, and at the end the S partial sums of a pixel are added in lane order,
+// scaled by 1/spp and :453 is applied.
+// (First version: any lane took any pixel's sample and added its radiance to the pixel's accumulator in LDS with ds_add_f32.
+// gfx950 executes an LDS float atomic at ~2 cycles per LANE — 131 LDS cycles per wave instruction, conflict or not — and the
+// kernel became LDS-bound: 33.6 ms.  profiles/r03_pool_v1_lds_atomics_pmc.txt.)
+//
+// Parity: each sample's arithmetic is exactly that of the fast closed-box round-synchronous kernel (the same inlined functions);
+// what differs is the ORDER in which a pixel's fp32 contributions are added — the reference adds accrad/spp sample by sample
+// (:451-:452), here every lane sums the contributions of the samples it happened to trace and the S partial sums are added at
+// the end — a reassociation, relative 1e-6 of the pixel value, far inside the fast-math tolerance and the reason
+// this kernel exists for MC_PT_MATH_FAST only.  It is deterministic: a wave's schedule depends on nothing outside the wave, and
+// the pixels a wave owns are the same for every tiling the host selects it for (pathtrace.hip).
+#pragma once
+#include "pathtrace_kernel.h"
+
+#ifndef MC_PT_POOL_WAVES
+#define MC_PT_POOL_WAVES 7   // waves per SIMD the register budget is set for (72 VGPRs; 6: 18.29 ms, 7: 18.11, 8: 18.68 at K2)
+#endif
+#ifndef MC_PT_POOL_HOT_VGPR
+#define MC_PT_POOL_HOT_VGPR false
+#endif
+
+namespace mc {
+namespace pt {
+
+constexpr uint32_t kPoolEntryFloats = 8;     // {rd.x, rd.y, rd.z, t | id (-1: nothing to trace), key0 = samp * maxDepth, -, -}
+constexpr uint32_t kPoolRecordFloats = 112;  // the 9 x 12 record floats, padded to a 16-byte multiple
+constexpr uint32_t kPoolWaveLdsFloats = 128u * kPoolEntryFloats;   // 64/S pixels x 2 batches x S entries
+constexpr size_t kPoolBlockLdsBytes = (kPoolRecordFloats + 4u * kPoolWaveLdsFloats) * sizeof(float);
+
+template <int S>
+__global__ void __launch_bounds__(256, MC_PT_POOL_WAVES) pathtrace_pool_kernel(PTArgs a) {
+    extern __shared__ float lds_dyn[];
+    float* lds_obj = lds_dyn;
+    stage_records(lds_obj, a.scene.obj, 9u, true);
+    constexpr uint32_t TW = WaveTile<S>::w, TH = WaveTile<S>::h, Ring = 2u * (uint32_t)S;
+    HotSlab hot;
+    hot.load<MC_PT_POOL_HOT_VGPR>(a.scene);   // (uniform operands: this kernel has no vector registers to spare for copies)
+    // A lane's pixel (pix = lane / S of the wave tile) and slot of a batch (sub = lane % S) never change.  What derives from them
+    // and is needed only now and then — the stash base, the tile row, the validity — is derived afresh from an opaque copy of
+    // the thread id where it is used, so that it does not occupy registers across the bounce loop (80 VGPRs = 6 waves per SIMD).
+    struct Lane { uint32_t lane, pix, sub, ty; bool valid; float* gstash; };
+    auto my_lane = [&](bool with_row) {
+        uint32_t tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        Lane q;
+        q.lane = tid & 63u; q.pix = q.lane / (uint32_t)S; q.sub = q.lane % (uint32_t)S;
+        const uint32_t wave = tid >> 6;
+        q.gstash = lds_dyn + kPoolRecordFloats + wave * kPoolWaveLdsFloats + q.pix * (Ring * kPoolEntryFloats);
+        q.ty = 0u; q.valid = false;
+        if (with_row) {   // pathTracer.comp:348
+            q.ty = blockIdx.y * (2u * TH) + (wave >> 1) * TH + q.pix / TW;
+            const uint32_t gxx = blockIdx.x * (2u * TW) + (wave & 1u) * TW + q.pix % TW;
+            q.valid = gxx < a.W && tile_row_to_storage(q.ty, a.row_begin, a.row_block, a.row_stride) < a.row_end;
+        }
+        return q;
+    };
+    // my pixel's coordinates (:349) stay: the RNG key of every bounce needs them
+    uint32_t gx, gy;
+    {
+        const uint32_t tid = threadIdx.x, wave = tid >> 6, pix = (tid & 63u) / (uint32_t)S;
+        gx = blockIdx.x * (2u * TW) + (wave & 1u) * TW + pix % TW;
+        const uint32_t ty = blockIdx.y * (2u * TH) + (wave >> 1) * TH + pix / TW;
+        const uint32_t srow = tile_row_to_storage(ty, a.row_begin, a.row_block, a.row_stride);
+        gy = a.H - 1u - ((gx < a.W && srow < a.row_end) ? srow : 0u);
+    }
+    const uint32_t n_batches = (a.sample_end - a.sample_begin + (uint32_t)S - 1u) / (uint32_t)S;
+    uint32_t batch = 0u;      // wave-uniform: batches produced; every pixel's stash has received batch * S entries
+    uint32_t ghead = 0u;      // entries my pixel's lanes have taken (the same value in all S lanes)
+    // ---- the state of a lane's path, and the radiance its paths have gathered
+    v3 ro{0, 0, 0}, rd{0, 0, 1}, accmat{1, 1, 1}, acc{0, 0, 0};
+    float emissive = 1.0f, t = 0.0f, occ[3] = {0.0f, 0.0f, 0.0f};
+    int id = 0;
+    uint32_t key = 0u, kend = 0u, krr = 0u;   // key0 + depth; key0 + maxDepth; key0 + 5 (:395: roulette while key > krr)
+    bool alive = false;
+    // every iteration either traces a bounce of a live lane, or consumes stash entries, or produces a batch: bounded
+    const unsigned long long max_iters = (unsigned long long)n_batches * S * (a.max_depth + 2ull) + 64ull;
+    for (unsigned long long it = 0; it < max_iters; it++) {
+        // ---- lanes whose path ended take their pixel's next camera rays
+        const unsigned long long deadm = __ballot(!alive);
+        if (deadm != 0ull) {
+            const Lane me = my_lane(false);
+            // the dead lanes of my pixel: S bits of the ballot starting at my pixel's first lane
+            const uint32_t gbits = (uint32_t)(deadm >> (me.lane - me.sub)) & (S == 32 ? ~0u : ((1u << (S & 31)) - 1u));
+            const uint32_t need = (uint32_t)__builtin_popcount(gbits);
+            uint32_t avail = batch * (uint32_t)S - ghead;
+            // one more batch when a pixel wants more rays than it has — and every pixel's ring has room for S more
+            if (batch < n_batches && __ballot(need > avail) != 0ull && __ballot(avail > (uint32_t)S) == 0ull) {
+                const Lane g = my_lane(true);
+                const uint32_t samp = a.sample_begin + batch * (uint32_t)S + g.sub;
+                const v3 crd = camera_ray<true>(a, gx, gy, samp);
+                v3 oc0[3];
+                float occ0[3], ct;
+#pragma unroll
+                for (int i = 0; i < 3; i++) { oc0[i] = v3{a.cam_oc[i][0], a.cam_oc[i][1], a.cam_oc[i][2]}; occ0[i] = a.cam_occ[i]; }
+                int cid = intersect_slab<true>(hot, a.lc, crd, ct, false, occ0, oc0);
+                // nothing to trace: a pixel outside the tile, a sample beyond the range; a camera ray that misses everything (:369)
+                // gathers nothing either
+                if (!(g.valid && samp < a.sample_end)) cid = -1;
+                float4* e = reinterpret_cast<float4*>(g.gstash + ((batch * (uint32_t)S + g.sub) & (Ring - 1u)) * kPoolEntryFloats);
+                e[0] = make_float4(crd.x, crd.y, crd.z, ct);
+                e[1] = make_float4(dm::as_float((uint32_t)cid), dm::as_float(samp * a.max_depth), 0.0f, 0.0f);
+                batch++;
+                avail += (uint32_t)S;
+            }
+            const uint32_t rank = (uint32_t)__builtin_popcount(gbits & ((1u << me.sub) - 1u));   // dead lanes of my pixel below me
+            if (!alive && rank < avail) {
+                const float4* q = reinterpret_cast<const float4*>(me.gstash + ((ghead + rank) & (Ring - 1u)) * kPoolEntryFloats);
+                const float4 q0 = q[0], q1 = q[1];
+                rd = v3{q0.x, q0.y, q0.z}; t = q0.w;
+                id = (int)dm::as_uint(q1.x);
+                key = dm::as_uint(q1.y); kend = key + a.max_depth; krr = key + 5u;
+                ro = a.lc;                                                  // :362
+                accmat = v3{1.0f, 1.0f, 1.0f}; emissive = 1.0f;             // :361, :365
+                alive = id >= 0;
+            }
+            ghead += need < avail ? need : avail;
+        }
+        // pool exhausted and every path ended?  (no lane alive but entries left: only empty entries were taken — go round again)
+        if (__ballot(alive) == 0ull && batch >= n_batches && __ballot(ghead != batch * (uint32_t)S) == 0ull) break;
+        // ---- one bounce of every live lane: prologue, material, intersection of the next depth (the rotated loop of trace_sample)
+        // (structured ifs, no break / continue: every extra exit edge of this block cost a dozen register copies at its merge)
+        if (alive) {
+            {
+                v3 x = ro + rd * t;                                               // :374
+                v3 xoc[3];                                                        // c_i - x (:317 at the next depth, :408 now)
+#pragma unroll
+                for (int i = 0; i < 3; i++) { xoc[i] = v3{hot.c[i][0], hot.c[i][1], hot.c[i][2]} - x; occ[i] = dot(xoc[i], xoc[i]); }
+                const float* obj = lds_obj + 12 * id;                             // per-lane fetch from LDS
+                const bool is_sphere = id >= 6;
+                v3 geo{obj[0], obj[1], obj[2]};
+                v3 col{obj[8], obj[9], obj[10]};
+                const int mat = (int)obj[11];                                     // = int(floor(m + 0.5)), :378/:384 (stage_records)
+                const float p = obj[7];                                           // = max(max(c.x, c.y), c.z), :394
+                v3 n = is_sphere ? normalize<true>(x - geo) : geo;                // :381/:387
+                const float dot_n_rd = dot(n, rd);
+                const uint32_t flip = ~dm::as_uint(dot_n_rd) & 0x80000000u;       // :390 nl = dot(n, rd) < 0 ? n : -n
+                v3 nl{dm::as_float(dm::as_uint(n.x) ^ flip), dm::as_float(dm::as_uint(n.y) ^ flip), dm::as_float(dm::as_uint(n.z) ^ flip)};
+                if (__ballot(obj[3] != 0.0f) != 0ull)                             // :391 (non-emitters add a zero: box_ok)
+                    acc = acc + (accmat * v3{obj[4], obj[5], obj[6]}) * emissive;
+                accmat = accmat * col;                                            // :392
+                v3 rnd = rand01(gx, gy, key);                                     // :393 (key = samp * maxDepth + depth)
+                bool go = true;
+                if (key > krr) {                                                  // :395 depth > 5
+                    go = !(rnd.z >= p);                                           // :396
+                    accmat = divs<true>(accmat, p);                               // :397 (unused when the path ends here)
+                }
+                if (go) {
+                ro = x;                                                           // :429, :434, :447
+                if (mat == 1) {                                                   // :400 diffuse
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {                                 // :403
+                        if (!((a.scene.emissive_mask >> i) & 1u)) continue;       // :407 (uniform)
+                        const float* ls = a.scene.obj + 12 * (6 + i);
+                        v3 le{ls[4], ls[5], ls[6]};
+                        float cos_a_max;
+                        v3 l = light_sample_direction<true>(xoc[i], occ[i], hot.r2[i], rnd, cos_a_max);   // :408-:413
+                        if (shadow_reaches_sphere<true>(hot, x, l, i, xoc[i], occ)) {                      // :420
+                            const float scale = __builtin_fmaxf(dot(l, nl), 0.0f) * (2.0f - (cos_a_max + cos_a_max));   // :421-:422
+                            acc = acc + (accmat * le) * scale;
+                        }
+                    }
+                    rd = cosine_bounce<true, true>(nl, rnd);                      // :426-:428
+                    emissive = 0.0f;                                              // :429
+                } else {                                                          // :432 mirror, :437 glass (box_ok: 2 or 3)
+                    rd = specular_bounce_fast(mat, rd, n, dot_n_rd, rnd.x, accmat);
+                    emissive = 1.0f;                                              // :447
+                }
+                key++;
+                go = key != kend;                                                 // :367 depth limit
+                if (go) {
+                    id = intersect_slab<true>(hot, ro, rd, t, false, occ, xoc);
+                    go = id >= 0;                                                 // :369
+                }
+                }
+                alive = go;
+            }
+        }
+    }
+    // ---- :452-:453: the S partial sums of a pixel, added in lane order by each of its lanes (all S copies identical)
+    float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    auto from_lane = [](float v, uint32_t src) {
+        return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src << 2), __float_as_int(v)));
+    };
+    const Lane fin = my_lane(true);
+    for (uint32_t k = 0; k < (uint32_t)S; k++) {
+        const uint32_t src = fin.lane - fin.sub + k;
+        sum.x += from_lane(acc.x, src); sum.y += from_lane(acc.y, src); sum.z += from_lane(acc.z, src);
+    }
+    sum.x *= a.inv_spp; sum.y *= a.inv_spp; sum.z *= a.inv_spp;
+    if (a.sample_end == a.spp) {
+        sum.x = dm::fpow<true>(dm::gmin(dm::gmax(sum.x, 0.0f), 1.0f), 0.45f) * 255.0f + 0.5f;
+        sum.y = dm::fpow<true>(dm::gmin(dm::gmax(sum.y, 0.0f), 1.0f), 0.45f) * 255.0f + 0.5f;
+        sum.z = dm::fpow<true>(dm::gmin(dm::gmax(sum.z, 0.0f), 1.0f), 0.45f) * 255.0f + 0.5f;
+    }
+    if (fin.valid && fin.sub == 0u) a.out[(size_t)fin.ty * a.W + gx] = sum;
+}
+
+template <int S> inline int launch_pool_one(const PTArgs& a, uint32_t tile_rows, hipStream_t s) {
+    dim3 grid((a.W + block_w<S>() - 1u) / block_w<S>(), (tile_rows + block_h<S>() - 1u) / block_h<S>());
+    hipLaunchKernelGGL(pathtrace_pool_kernel<S>, grid, dim3(256), kPoolBlockLdsBytes, s, a);
+    return MC_OK;
+}
+// variant 4 of launch_fast: S as chosen by the host (1, 4 or 16 lanes per pixel in a batch)
+inline int launch_pool(const PTArgs& a, int S, uint32_t tile_rows, hipStream_t s) {
+    if (S == 1) return launch_pool_one<1>(a, tile_rows, s);
+    if (S == 4) return launch_pool_one<4>(a, tile_rows, s);
+    if (S == 16) return launch_pool_one<16>(a, tile_rows, s);
+    return MC_ERR_INVALID_ARGUMENT;
+}
+
+}  // namespace pt
+}  // namespace mc
