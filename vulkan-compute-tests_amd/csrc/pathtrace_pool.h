@@ -36,8 +36,9 @@
 namespace mc {
 namespace pt {
 
-constexpr uint32_t kPoolEntryFloats = 8;     // {rd.x, rd.y, rd.z, t | id (-1: nothing to trace), key0 = samp * maxDepth, -, -}
-constexpr uint32_t kPoolRecordFloats = 112;  // the 9 x 12 record floats, padded to a 16-byte multiple
+constexpr uint32_t kPoolEntryFloats = 8;     // {rd.x, rd.y, rd.z, t | id (-1: nothing to trace), key0 = samp * maxDepth, rnd.x, rnd.y of key0}
+constexpr uint32_t kPoolRecordStride = 16;   // floats per staged record: {geo.xyz, p | colour.rgb, material + 256 * emits | emission.xyz, -}
+constexpr uint32_t kPoolRecordFloats = 9u * kPoolRecordStride;
 constexpr uint32_t kPoolWaveLdsFloats = 128u * kPoolEntryFloats;   // 64/S pixels x 2 batches x S entries
 constexpr size_t kPoolBlockLdsBytes = (kPoolRecordFloats + 4u * kPoolWaveLdsFloats) * sizeof(float);
 
@@ -45,21 +46,32 @@ template <int S>
 __global__ void __launch_bounds__(256, MC_PT_POOL_WAVES) pathtrace_pool_kernel(PTArgs a) {
     extern __shared__ float lds_dyn[];
     float* lds_obj = lds_dyn;
-    stage_records(lds_obj, a.scene.obj, 9u, true);
+    // The 9 records, re-packed for two 16-byte reads per bounce at address id << 6: the plane normal / sphere centre with the
+    // roulette probability max(max(c.x, c.y), c.z) (:394), the colour with the material code int(floor(m + 0.5)) (:378/:384)
+    // and an "emits" flag as integer bits — the same fp32 operations on the same operands as evaluating them at every bounce.
+    if (threadIdx.x < 9u) {
+        const float* o = a.scene.obj + 12u * threadIdx.x;
+        float* r = lds_obj + kPoolRecordStride * threadIdx.x;
+        r[0] = o[0]; r[1] = o[1]; r[2] = o[2]; r[3] = dm::gmax(dm::gmax(o[8], o[9]), o[10]);
+        r[4] = o[8]; r[5] = o[9]; r[6] = o[10];
+        const uint32_t emits = (o[4] != 0.0f || o[5] != 0.0f || o[6] != 0.0f) ? 256u : 0u;
+        r[7] = dm::as_float((uint32_t)(int)__builtin_floorf(o[11] + 0.5f) | emits);
+        r[8] = o[4]; r[9] = o[5]; r[10] = o[6]; r[11] = 0.0f;
+    }
+    __syncthreads();
     constexpr uint32_t TW = WaveTile<S>::w, TH = WaveTile<S>::h, Ring = 2u * (uint32_t)S;
     HotSlab hot;
     hot.load<MC_PT_POOL_HOT_VGPR>(a.scene);   // (uniform operands: this kernel has no vector registers to spare for copies)
     // A lane's pixel (pix = lane / S of the wave tile) and slot of a batch (sub = lane % S) never change.  What derives from them
     // and is needed only now and then — the stash base, the tile row, the validity — is derived afresh from an opaque copy of
     // the thread id where it is used, so that it does not occupy registers across the bounce loop (80 VGPRs = 6 waves per SIMD).
-    struct Lane { uint32_t lane, pix, sub, ty; bool valid; float* gstash; };
+    struct Lane { uint32_t lane, pix, sub, ty; bool valid; };
     auto my_lane = [&](bool with_row) {
         uint32_t tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         Lane q;
         q.lane = tid & 63u; q.pix = q.lane / (uint32_t)S; q.sub = q.lane % (uint32_t)S;
         const uint32_t wave = tid >> 6;
-        q.gstash = lds_dyn + kPoolRecordFloats + wave * kPoolWaveLdsFloats + q.pix * (Ring * kPoolEntryFloats);
         q.ty = 0u; q.valid = false;
         if (with_row) {   // pathTracer.comp:348
             q.ty = blockIdx.y * (2u * TH) + (wave >> 1) * TH + q.pix / TW;
@@ -68,8 +80,10 @@ __global__ void __launch_bounds__(256, MC_PT_POOL_WAVES) pathtrace_pool_kernel(P
         }
         return q;
     };
-    // my pixel's coordinates (:349) stay: the RNG key of every bounce needs them
+    // my pixel's coordinates (:349) stay: the RNG key of every bounce needs them; so does the base of its stash
     uint32_t gx, gy;
+    float* const gstash = lds_dyn + kPoolRecordFloats + (threadIdx.x >> 6) * kPoolWaveLdsFloats +
+                          ((threadIdx.x & 63u) / (uint32_t)S) * (Ring * kPoolEntryFloats);
     {
         const uint32_t tid = threadIdx.x, wave = tid >> 6, pix = (tid & 63u) / (uint32_t)S;
         gx = blockIdx.x * (2u * TW) + (wave & 1u) * TW + pix % TW;
@@ -85,6 +99,10 @@ __global__ void __launch_bounds__(256, MC_PT_POOL_WAVES) pathtrace_pool_kernel(P
     float emissive = 1.0f, t = 0.0f, occ[3] = {0.0f, 0.0f, 0.0f};
     int id = 0;
     uint32_t key = 0u, kend = 0u, krr = 0u;   // key0 + depth; key0 + maxDepth; key0 + 5 (:395: roulette while key > krr)
+    // rand01 of the bounce about to be traced (:393).  It is drawn at the END of the previous bounce, together with the Russian
+    // roulette decision of :396 (the hit — hence p — is known there: the loop is rotated), so that a path the roulette ends
+    // frees its lane at the end of an iteration, not a third of the way into the next one.
+    float rx = 0.0f, ry = 0.0f;
     bool alive = false;
     // every iteration either traces a bounce of a live lane, or consumes stash entries, or produces a batch: bounded
     const unsigned long long max_iters = (unsigned long long)n_batches * S * (a.max_depth + 2ull) + 64ull;
@@ -110,19 +128,21 @@ __global__ void __launch_bounds__(256, MC_PT_POOL_WAVES) pathtrace_pool_kernel(P
                 // nothing to trace: a pixel outside the tile, a sample beyond the range; a camera ray that misses everything (:369)
                 // gathers nothing either
                 if (!(g.valid && samp < a.sample_end)) cid = -1;
-                float4* e = reinterpret_cast<float4*>(g.gstash + ((batch * (uint32_t)S + g.sub) & (Ring - 1u)) * kPoolEntryFloats);
+                float4* e = reinterpret_cast<float4*>(gstash + ((batch * (uint32_t)S + g.sub) & (Ring - 1u)) * kPoolEntryFloats);
                 e[0] = make_float4(crd.x, crd.y, crd.z, ct);
-                e[1] = make_float4(dm::as_float((uint32_t)cid), dm::as_float(samp * a.max_depth), 0.0f, 0.0f);
+                const v3 r0 = rand01(gx, gy, samp * a.max_depth);           // :393 at depth 0 (no roulette there: z unused)
+                e[1] = make_float4(dm::as_float((uint32_t)cid), dm::as_float(samp * a.max_depth), r0.x, r0.y);
                 batch++;
                 avail += (uint32_t)S;
             }
             const uint32_t rank = (uint32_t)__builtin_popcount(gbits & ((1u << me.sub) - 1u));   // dead lanes of my pixel below me
             if (!alive && rank < avail) {
-                const float4* q = reinterpret_cast<const float4*>(me.gstash + ((ghead + rank) & (Ring - 1u)) * kPoolEntryFloats);
+                const float4* q = reinterpret_cast<const float4*>(gstash + ((ghead + rank) & (Ring - 1u)) * kPoolEntryFloats);
                 const float4 q0 = q[0], q1 = q[1];
                 rd = v3{q0.x, q0.y, q0.z}; t = q0.w;
                 id = (int)dm::as_uint(q1.x);
                 key = dm::as_uint(q1.y); kend = key + a.max_depth; krr = key + 5u;
+                rx = q1.z; ry = q1.w;
                 ro = a.lc;                                                  // :362
                 accmat = v3{1.0f, 1.0f, 1.0f}; emissive = 1.0f;             // :361, :365
                 alive = id >= 0;
@@ -139,26 +159,27 @@ __global__ void __launch_bounds__(256, MC_PT_POOL_WAVES) pathtrace_pool_kernel(P
                 v3 xoc[3];                                                        // c_i - x (:317 at the next depth, :408 now)
 #pragma unroll
                 for (int i = 0; i < 3; i++) { xoc[i] = v3{hot.c[i][0], hot.c[i][1], hot.c[i][2]} - x; occ[i] = dot(xoc[i], xoc[i]); }
-                const float* obj = lds_obj + 12 * id;                             // per-lane fetch from LDS
+                const float4* obj = reinterpret_cast<const float4*>(lds_obj + kPoolRecordStride * (uint32_t)id);   // per-lane fetch
+                const float4 o0 = obj[0], o1 = obj[1];
                 const bool is_sphere = id >= 6;
-                v3 geo{obj[0], obj[1], obj[2]};
-                v3 col{obj[8], obj[9], obj[10]};
-                const int mat = (int)obj[11];                                     // = int(floor(m + 0.5)), :378/:384 (stage_records)
-                const float p = obj[7];                                           // = max(max(c.x, c.y), c.z), :394
+                v3 geo{o0.x, o0.y, o0.z};
+                v3 col{o1.x, o1.y, o1.z};
+                const uint32_t mbits = dm::as_uint(o1.w);
+                const int mat = (int)(mbits & 255u);                              // :378/:384
+                const float p = o0.w;                                             // :394
                 v3 n = is_sphere ? normalize<true>(x - geo) : geo;                // :381/:387
                 const float dot_n_rd = dot(n, rd);
                 const uint32_t flip = ~dm::as_uint(dot_n_rd) & 0x80000000u;       // :390 nl = dot(n, rd) < 0 ? n : -n
                 v3 nl{dm::as_float(dm::as_uint(n.x) ^ flip), dm::as_float(dm::as_uint(n.y) ^ flip), dm::as_float(dm::as_uint(n.z) ^ flip)};
-                if (__ballot(obj[3] != 0.0f) != 0ull)                             // :391 (non-emitters add a zero: box_ok)
-                    acc = acc + (accmat * v3{obj[4], obj[5], obj[6]}) * emissive;
-                accmat = accmat * col;                                            // :392
-                v3 rnd = rand01(gx, gy, key);                                     // :393 (key = samp * maxDepth + depth)
-                bool go = true;
-                if (key > krr) {                                                  // :395 depth > 5
-                    go = !(rnd.z >= p);                                           // :396
-                    accmat = divs<true>(accmat, p);                               // :397 (unused when the path ends here)
+                if (__ballot(mbits >= 256u) != 0ull) {                            // :391 (non-emitters add a zero: box_ok)
+                    const float4 o2 = obj[2];
+                    acc = acc + (accmat * v3{o2.x, o2.y, o2.z}) * emissive;
                 }
-                if (go) {
+                accmat = accmat * col;                                            // :392
+                const v3 rnd{rx, ry, 0.0f};                                       // :393 (drawn at the end of the previous bounce)
+                if (key > krr) accmat = divs<true>(accmat, p);                    // :395, :397 (:396 was decided there too)
+                bool go = true;
+                {
                 ro = x;                                                           // :429, :434, :447
                 if (mat == 1) {                                                   // :400 diffuse
 #pragma unroll
@@ -184,6 +205,19 @@ __global__ void __launch_bounds__(256, MC_PT_POOL_WAVES) pathtrace_pool_kernel(P
                 if (go) {
                     id = intersect_slab<true>(hot, ro, rd, t, false, occ, xoc);
                     go = id >= 0;                                                 // :369
+                }
+                if (go) {                                                         // the next bounce's random numbers and roulette
+                    const v3 rn = rand01(gx, gy, key);                            // :393 (key = samp * maxDepth + depth)
+                    rx = rn.x; ry = rn.y;
+                    if (key > krr) {                                              // :395 depth > 5
+                        const float4* nobj = reinterpret_cast<const float4*>(lds_obj + kPoolRecordStride * (uint32_t)id);
+                        go = !(rn.z >= nobj[0].w);                                // :396
+                        // a path the roulette ends has still gathered the emission of this hit (:391 precedes :396)
+                        if (__ballot(!go && dm::as_uint(nobj[1].w) >= 256u) != 0ull) {
+                            const float4 o2 = nobj[2];
+                            if (!go) acc = acc + (accmat * v3{o2.x, o2.y, o2.z}) * emissive;
+                        }
+                    }
                 }
                 }
                 alive = go;
