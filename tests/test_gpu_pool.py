@@ -1,0 +1,91 @@
+"""The sample-pool path tracer kernel (csrc/pathtrace_pool.h; MC_PT_MATH_FAST, closed-box scenes, whole sample ranges, tiles that
+keep the whole image's wave tiles).  Every sample's arithmetic is the round-synchronous closed-box kernel's; what differs is the
+order in which a pixel's fp32 contributions are added.  So: (1) against that kernel the storage buffer agrees to the last few
+ulps except where a rounding forks a path (different inlining contexts contract differently), (2) against the oracle it obeys
+the fast-math tolerance, (3) it is deterministic and tiling-invariant bit for bit, (4) everything outside its domain runs the
+round-synchronous kernels exactly as before."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def fast(ctx, B, W, H, spp, flags=0, **kw):
+    return ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, flags=flags, **kw))
+
+
+@pytest.mark.parametrize("W,H,spp,depth", [(8, 8, 16, 12), (33, 9, 37, 12), (3, 5, 1, 12), (1, 1, 500, 12), (64, 48, 100, 12),
+                                           (40, 24, 70, 7), (40, 24, 33, 2), (40, 24, 20, 1), (20, 12, 9, 15), (300, 200, 64, 12)])
+def test_pool_kernel_agrees_with_the_round_synchronous_kernel(ctx, B, W, H, spp, depth):
+    pool = fast(ctx, B, W, H, spp, max_depth=depth)[..., :3].astype(np.float64)
+    rounds = fast(ctx, B, W, H, spp, flags=B.PT_NO_POOL_KERNEL, max_depth=depth)[..., :3].astype(np.float64)
+    d = np.abs(pool - rounds)
+    assert np.isfinite(pool).all()
+    # a reassociated sum of spp x ~10 fp32 terms: a few 1e-5 of an 8-bit unit; a forked sample moves ONE pixel by up to 255 / spp
+    assert d.mean() <= 2e-3, d.mean()
+    assert (d > 1e-2).mean() <= 2e-3, (d > 1e-2).mean()
+
+
+def test_pool_kernel_is_deterministic_and_tiling_invariant(ctx, B):
+    """The N-GPU == 1-GPU contract in fast math: a wave owns the same 2 x 2 pixels whatever the tile, its schedule depends on
+    nothing else, so tiles equal the whole image's rows bit for bit — contiguous halves, and the interleaved 8-row blocks of
+    the multi-GPU split (ranks 0..3 of 4)."""
+    W, H, spp = 70, 48, 53
+    whole = fast(ctx, B, W, H, spp)
+    assert np.array_equal(bits(whole), bits(fast(ctx, B, W, H, spp)))
+    for (r0, r1) in [(0, 24), (24, 48), (10, 30), (46, 48)]:
+        assert np.array_equal(bits(fast(ctx, B, W, H, spp, row_begin=r0, row_end=r1)), bits(whole[r0:r1])), (r0, r1)
+    blk, n = B.lib().mc_row_block(), 4
+    for rank in range(n):
+        tile = fast(ctx, B, W, H, spp, row_begin=rank * blk, row_end=H, row_block=blk, row_stride=n * blk)
+        rows = np.array([r for r in range(H) if (r // blk) % n == rank])
+        assert np.array_equal(bits(tile), bits(whole[rows])), rank
+
+
+def test_outside_its_domain_the_round_synchronous_kernels_run(ctx, B):
+    """Partial sample ranges (the accumulator continues in the buffer), forced widths, tiles that cut a wave tile, scenes that are
+    not a closed box: the default flags and MC_PT_NO_POOL_KERNEL must give the same bits, i.e. the same kernel ran."""
+    W, H, spp = 40, 24, 19
+    cases = [dict(sample_begin=0, sample_end=7), dict(row_begin=5, row_end=17), dict(row_begin=0, row_end=23)]
+    for kw in cases:
+        assert np.array_equal(bits(fast(ctx, B, W, H, spp, **kw)), bits(fast(ctx, B, W, H, spp, flags=B.PT_NO_POOL_KERNEL, **kw))), kw
+    for s in (1, 4, 16):
+        a = fast(ctx, B, W, H, spp, flags=B.pt_force_s(s))
+        assert np.array_equal(bits(a), bits(fast(ctx, B, W, H, spp, flags=B.pt_force_s(s) | B.PT_NO_POOL_KERNEL))), s
+    # progressive ranges still compose bit-exactly in fast math (round-synchronous kernels on both sides)
+    part = fast(ctx, B, W, H, spp, sample_begin=0, sample_end=7)
+    part = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, sample_begin=7, sample_end=spp), acc=part)
+    assert np.array_equal(bits(part), bits(fast(ctx, B, W, H, spp, flags=B.PT_NO_POOL_KERNEL)))
+
+
+def test_pool_kernel_within_the_fast_tolerance_of_the_oracle(ctx, B, O):
+    """96 x 64 at 256 spp against the oracle with libm: the small-size bound the other fast kernels are held to
+    (tests/test_gpu_parity.py): RMSE <= 0.4, 99.9-percentile L2 <= 4, no bias."""
+    W, H, spp = 96, 64, 256
+    out = fast(ctx, B, W, H, spp)[..., :3].astype(np.float64)
+    ref = O.pathtrace(W, H, spp, math_mode=O.MATH_LIBM)[..., :3].astype(np.float64)
+    d = out - ref
+    rmse = float(np.sqrt((d ** 2).mean()))
+    p999 = float(np.percentile(np.sqrt((d ** 2).sum(-1)), 99.9))
+    print(f"pool 96x64x256 vs oracle(libm): rmse {rmse:.4f}  p99.9 L2 {p999:.3f}  mean diff {d.mean():+.5f}")
+    assert rmse <= 0.4 and p999 <= 4.0 and abs(d.mean()) < 0.05
+
+
+def test_pool_kernel_k3_band_at_4096_spp(ctx, B, O):
+    """K3 (3840x2560 at 4096 spp) on one 8-row block in fast math — the kernel `bench.py --config K3` times: RNG keys up to
+    49 151, 256 batches per pixel, rows far from the tile origin — within the fast tolerance of the oracle with libm
+    (1.26e8 samples: about 15 s of the oracle)."""
+    W, H, spp = 3840, 2560, 4096
+    blk = B.lib().mc_row_block()
+    r0 = 161 * blk
+    ref = O.pathtrace(W, H, spp, math_mode=O.MATH_LIBM, row_begin=r0, row_end=r0 + blk)[..., :3].astype(np.float64)
+    band = fast(ctx, B, W, H, spp, row_begin=r0, row_end=r0 + blk)[..., :3].astype(np.float64)
+    d = band - ref
+    rmse = float(np.sqrt((d ** 2).mean()))
+    p999 = float(np.percentile(np.sqrt((d ** 2).sum(-1)), 99.9))
+    print(f"pool K3 band vs oracle(libm): rmse {rmse:.4f}  p99.9 L2 {p999:.3f}  mean diff {d.mean():+.5f}")
+    assert rmse <= 0.5 and p999 <= 4.0 and abs(d.mean()) < 0.02
