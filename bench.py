@@ -28,6 +28,7 @@ One JSON line is printed by rank 0.
    receives only this repository) timed on this host's cores over a bounded sample of the same workload.
 """
 import argparse
+import copy
 import json
 import os
 import sys
@@ -237,42 +238,66 @@ def main():
     owns = S.owns_rows(p)                                     # False for a rank beyond the last row block (renders nothing)
     rows_local = B.tile_rows(p)
     rows_padded = S.padded_tile_rows(H, n) if n > 1 else rows_local
-    tile = torch.zeros((rows_padded, W, 4), dtype=torch.float32, device="cuda")
-    iters_t = torch.zeros((rows_padded, W), dtype=torch.int32, device="cuda") if not is_pt else None
+    # What a rank renders into, and what it sends to rank 0 (S.Exchange: receive buffers allocated once, the gather asynchronous,
+    # rank 0's re-assembly on a side stream, two buffer sets — step i's exchange overlaps step i + 1's render):
+    #   path tracer: the fp32 vec4 tile (16 B/pixel; samples are never split across ranks);
+    #   Mandelbrot, N > 1: ONLY the iteration counts — uint16 for max_iter <= 65535 (2 B/pixel) — from which rank 0 rebuilds the
+    #   vec4 storage buffer through the colour table (the colour is a function of the count alone); N = 1: vec4 + counts.
+    narrow = (not is_pt) and n > 1 and p.max_iter <= 65535
+    if is_pt:
+        ex = S.Exchange(rank, n, (rows_padded, W, 4), torch.float32, "cuda")
+    elif n > 1:
+        if narrow:
+            p.flags |= B.MANDEL_ITERS_U16
+            ex = S.Exchange(rank, n, (rows_padded, W, 2), torch.uint8, "cuda")
+        else:
+            ex = S.Exchange(rank, n, (rows_padded, W), torch.int32, "cuda")
+    else:
+        ex = S.Exchange(rank, n, (rows_padded, W, 4), torch.float32, "cuda")
+    iters_t = torch.zeros((rows_padded, W), dtype=torch.int32, device="cuda") if (not is_pt and n == 1) else None
     full = torch.empty((H, W, 4), dtype=torch.float32, device="cuda") if n > 1 and rank == 0 else None
+    full_iters = torch.empty((H, W), dtype=torch.int32, device="cuda") if (n > 1 and rank == 0 and not is_pt) else None
 
     ev_k0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev_k1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev_g1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
-    def step(i=None):
+    def assemble(recv, stream_handle):                        # rank 0, on the exchange's side stream
+        if is_pt:
+            S.assemble_device(ctx, recv, W, H, n, full, stream=stream_handle)
+        else:
+            q = copy.copy(p)
+            q.row_begin, q.row_end, q.row_block, q.row_stride = 0, H, 0, 0
+            S.assemble_mandelbrot_device(ctx, q, recv, n, full, full_iters, stream=stream_handle)
+
+    def step(i=None, k=0):
+        tile = ex.tile(k)
         if i is not None:
             ev_k0[i].record()
         if owns:
             if is_pt:
                 ctx.pathtrace_device(p, tile.data_ptr(), stream=stream)
+            elif n > 1:
+                ctx.mandelbrot_device(p, 0, tile.data_ptr(), stream=stream)
             else:
                 ctx.mandelbrot_device(p, tile.data_ptr(), iters_t.data_ptr(), stream=stream)
         if i is not None:
             ev_k1[i].record()
         if n > 1:
-            gathered = S.gather_tiles(tile, rank, n)          # RCCL gather of the fp32 tiles to rank 0
-            if rank == 0:
-                S.assemble_device(ctx, gathered, W, H, n, full, stream=stream)
-            if i is not None:
-                ev_g1[i].record()
+            ex.submit(k, assemble, ev_g1[i] if i is not None else None)
 
     def fence():
+        ex.finish()
         if n > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for w in range(args.warmup):
+        step(None, w)
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step(i, args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
     if n > 1:
@@ -282,13 +307,19 @@ def main():
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_k0, ev_k1)]))
     sclk_mhz = ctx.measure_clock() if rank == 0 else None   # the clock this box holds under VALU load (boxes differ by >10 %)
     gather_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_k1, ev_g1)])) if n > 1 else 0.0
-    gather_bytes = int(tile.numel() * tile.element_size()) if n > 1 else 0   # what every rank sends to rank 0 per step
+    gather_bytes = int(ex.bytes_per_rank) if n > 1 else 0     # what every rank sends to rank 0 per step
+    tile = ex.tiles[(args.warmup + args.steps - 1) % len(ex.tiles)]   # the last step's tile (units are counted from it)
 
     # ---- units ------------------------------------------------------------------------------------
     if is_pt:
         local_units = W * rows_local * p.spp
     else:
-        it = iters_t[:rows_local].to(torch.int64)
+        if n == 1:
+            it = iters_t[:rows_local].to(torch.int64)
+        elif narrow:
+            it = tile[:rows_local].contiguous().view(torch.int16).to(torch.int64).squeeze(-1) & 0xffff
+        else:
+            it = tile[:rows_local].to(torch.int64)
         M = p.max_iter
         local_units = int(torch.where(it < M, it + 1, torch.full_like(it, M)).sum().item())   # loop bodies of the REFERENCE algorithm
         if n > 1:
@@ -314,9 +345,10 @@ def main():
     # ---- optional self-check: N-rank image == single-GPU image, bit for bit (outside the timed region) ----------
     verified = None
     if args.verify and n > 1 and rank == 0:
-        import copy
         q = copy.copy(p)
         q.row_begin, q.row_end, q.row_block, q.row_stride = 0, H, 0, 0
+        if not is_pt:
+            q.flags &= ~B.MANDEL_ITERS_U16
         single = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
         if is_pt:
             ctx.pathtrace_device(q, single.data_ptr(), stream=stream)
@@ -357,11 +389,14 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_name, "baseline_config": cfg_name, "image": [W, H], "rows_per_gpu": rows_local,
                        "tiling": "whole image" if n == 1 else f"interleaved {ROW_BLOCK}-row blocks, RCCL gather to rank 0",
+                       **({"exchange": ("fp32 vec4 tiles (16 B/pixel)" if is_pt else
+                                        ("uint16" if narrow else "uint32") + " iteration counts; rank 0 rebuilds the vec4 buffer through the colour table") +
+                                       "; asynchronous gather + re-assembly on a side stream, overlapping the next step's render"} if n > 1 else {}),
                        "device": dev_name, "compute_units": cus, "sclk_mhz_under_valu_load": round(sclk_mhz, 1),
                        **({"unit_note": "reference-equivalent pixel-iterations (see roofline.lane_ops.note)"} if not is_pt else {}),
                        **({"backend": backend, "world_size": dist.get_world_size(), "ranks": ranks_info,
                            "gather_ms_rank0": round(gather_ms, 4), "gather_bytes_per_rank": gather_bytes,
-                           "gather_note": "kernel end -> gathered + re-assembled on rank 0; includes waiting for the slowest rank"}
+                           "gather_note": "kernel end -> gathered + re-assembled on rank 0 (side stream; overlaps the next render); includes waiting for the slowest rank"}
                           if n > 1 else {}),
                        **({"rehearsal": "MC_BENCH_BACKEND=gloo: ranks share GPUs, gather staged through the host; "
                                         "timings are NOT a measurement"} if backend != "nccl" and n > 1 else {}),

@@ -62,7 +62,9 @@ int mc_context_measure_clock(mc_context* ctx, double* sclk_mhz);
  *      MandelbrotApp::createCommandBuffer (src/mandelbrotApp.h:137-147) ----------------------------- */
 enum { MC_PRECISION_F32 = 0, MC_PRECISION_DS = 1 /* two-float, emulateDouble.h.glsl:59-139 */ };
 enum {
-    MC_MANDEL_FMA = 1u << 0 /* NON-PARITY diagnostic: allow fp contraction in the fp32 loop */
+    MC_MANDEL_FMA = 1u << 0,      /* NON-PARITY diagnostic: allow fp contraction in the fp32 loop */
+    MC_MANDEL_ITERS_U16 = 1u << 1 /* device form: d_iters is a uint16_t plane (max_iter <= 65535) — the multi-GPU exchange  */
+                                  /* format, half of the 4-B plane and an eighth of the vec4 (mc_mandelbrot_assemble_...)  */
 };
 
 typedef struct mc_mandelbrot_params {
@@ -201,6 +203,14 @@ uint32_t mc_tile_rows(uint32_t row_begin, uint32_t row_end, uint32_t row_block, 
 int mc_deinterleave_rows_device_async(mc_context* ctx, const void* d_tiles, uint32_t width, uint32_t height,
                                       uint32_t n_tiles, uint32_t row_block, uint32_t tile_rows_padded,
                                       uint32_t bytes_per_pixel, void* d_out, void* stream);
+
+/* Mandelbrot exchange on the root: d_tiles holds n_tiles interleaved tiles of ITERATION COUNTS (iters_bytes = 2: uint16_t,
+ * MC_MANDEL_ITERS_U16; 4: uint32_t) laid out as mc_deinterleave_rows_device_async expects; writes the whole image's storage
+ * buffer d_rgba_f32 (lut[n] per pixel: exactly what the render kernel writes for that count, mandelbrot.comp:50-59) and/or its
+ * uint32 count plane d_iters.  The ranks of a multi-GPU render then exchange 2-4 B/pixel instead of 16. */
+int mc_mandelbrot_assemble_device_async(mc_context* ctx, const mc_mandelbrot_params* p, const void* d_tiles, uint32_t iters_bytes,
+                                        uint32_t n_tiles, uint32_t row_block, uint32_t tile_rows_padded, void* d_rgba_f32,
+                                        void* d_iters, void* stream);
 
 /* ---- single-process multi-GPU render (north_star: row tiles + RCCL gather to rank 0) --------------
  * Renders the whole image on n_devices GPUs of this node (interleaved row blocks), gathers

@@ -103,3 +103,18 @@ def test_four_rank_rehearsal_strong_scaling_with_per_rank_evidence():
     assert [r["rank"] for r in c["ranks"]] == [0, 1, 2, 3] and all(r["world_size_seen"] == 4 for r in c["ranks"])
     assert [r["rows"] for r in c["ranks"]] == [64, 64, 64, 58] and sum(r["units_per_step"] for r in c["ranks"]) == 384 * 250 * 6
     assert all(r["kernel_ms"] > 0 for r in c["ranks"]) and c["gather_ms_rank0"] > 0
+
+
+def test_two_rank_rehearsal_mandelbrot_exchanges_iteration_counts():
+    """K4 geometry cut down (768 x 520, M = 50 000) over 2 ranks (gloo rehearsal): the ranks send 16-bit iteration counts — 2 B
+    per pixel, an eighth of the vec4 tile — rank 0 rebuilds the storage buffer through the colour table, and the result is
+    bit-identical to the single-GPU render."""
+    launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29551"]
+    d = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "K4", "--width", "768", "--height", "520", "--verify"],
+                  env_extra={"MC_BENCH_BACKEND": "gloo"}, launcher=launcher)
+    check_common(d, 2, 2, 1, scaling="strong")
+    c = d["config"]
+    assert c["verified_equal_to_single_gpu"] is True and "uint16" in c["exchange"]
+    assert c["gather_bytes_per_rank"] == 264 * 768 * 2      # rank 0's tile: 33 of the 65 row blocks
+    assert sum(r["units_per_step"] for r in c["ranks"]) == round(d["value"] * d["ms_per_step"] * 1e-3)

@@ -1,0 +1,125 @@
+"""The multi-GPU exchange (north_star: row tiles + RCCL gather to rank 0).
+
+On the one-GPU box: the root side of the Mandelbrot exchange — ranks send ITERATION COUNTS (uint16 / uint32), rank 0 rebuilds
+the vec4 storage buffer through the colour table — checked by rendering the ranks' interleaved tiles one after the other on the
+one device, laying them out as a gather would, and comparing with the whole-image render bit for bit.
+On a box with >= 2 GPUs (skipped otherwise; the first multi-GPU box validates itself): mc_multi_*(2) memcmp-equal to the
+single-GPU render for both hot paths, and `bench.py --gpus 2 --verify` on the RCCL backend."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def n_devices():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("W,H,M,n,ds", [(100, 70, 300, 2, False), (33, 20, 100, 8, False), (64, 601, 1000, 4, False),
+                                        (48, 40, 70000, 2, False), (40, 24, 500, 2, True)])
+def test_mandelbrot_exchange_of_iteration_counts(ctx, B, W, H, M, n, ds):
+    """(33, 20, n = 8): ranks 3..7 own no rows; (48, 40, 70000): max_iter beyond 16 bits, 4-byte counts; ds: two-float."""
+    import torch
+    kw = dict(max_iter=M)
+    if ds:
+        kw.update(precision=B.PRECISION_DS, centre=(-0.7436438870371587, 0.13182590420531198), scale=(1e-6, 1e-6))
+    whole_rgba, whole_it = ctx.mandelbrot(B.mandelbrot_params(W, H, **kw))
+    blk = B.lib().mc_row_block()
+    padded = len([r for r in range(H) if (r // blk) % n == 0])
+    narrow = M <= 65535
+    tiles = torch.zeros((n, padded, W, 2), dtype=torch.uint8, device="cuda") if narrow else \
+        torch.zeros((n, padded, W), dtype=torch.int32, device="cuda")
+    for rank in range(n):
+        p = B.mandelbrot_params(W, H, row_begin=rank * blk, row_end=H, row_block=blk, row_stride=n * blk, **kw)
+        if p.row_begin >= p.row_end:
+            continue
+        if narrow:
+            p.flags |= B.MANDEL_ITERS_U16
+        ctx.mandelbrot_device(p, 0, tiles[rank].data_ptr())
+    full = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    full_it = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    q = B.mandelbrot_params(W, H, **kw)
+    ctx.mandelbrot_assemble_device(q, tiles.data_ptr(), 2 if narrow else 4, n, blk, padded, full.data_ptr(), full_it.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(full_it.cpu().numpy().astype(np.uint32), whole_it)
+    assert np.array_equal(bits(full.cpu().numpy()), bits(whole_rgba))
+    # counts only / colours only
+    full.zero_()
+    ctx.mandelbrot_assemble_device(q, tiles.data_ptr(), 2 if narrow else 4, n, blk, padded, full.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(full.cpu().numpy()), bits(whole_rgba))
+
+
+def test_mandelbrot_exchange_argument_errors(ctx, B):
+    import ctypes as C
+    import torch
+    L = B.lib()
+    t = torch.zeros((1, 8, 8, 2), dtype=torch.uint8, device="cuda")
+    o = torch.zeros((8, 8, 4), dtype=torch.float32, device="cuda")
+    p = B.mandelbrot_params(8, 8, max_iter=100)
+    call = lambda pp, ib, dt, do: L.mc_mandelbrot_assemble_device_async(ctx._h, C.byref(pp), dt, ib, 1, 8, 8, do, None, None)
+    assert call(p, 3, t.data_ptr(), o.data_ptr()) == 1            # 2 or 4 bytes per count
+    assert call(p, 2, None, o.data_ptr()) == 1 and call(p, 2, t.data_ptr(), None) == 1
+    big = B.mandelbrot_params(8, 8, max_iter=70000)
+    assert call(big, 2, t.data_ptr(), o.data_ptr()) == 1          # 16-bit counts cannot hold max_iter
+    big.flags |= B.MANDEL_ITERS_U16
+    with pytest.raises(B.McError):
+        ctx.mandelbrot_device(big, 0, t.data_ptr())
+    # a 16-B row length with a 4-B offset base: the de-interleave must take the 4-B granule kernel
+    src = torch.arange(2 * 16 * 8, dtype=torch.int32, device="cuda").reshape(2, 16, 8)
+    flat = torch.zeros(1 + 2 * 16 * 8, dtype=torch.int32, device="cuda")
+    flat[1:] = src.reshape(-1)
+    out = torch.zeros((32, 8), dtype=torch.int32, device="cuda")
+    ctx.deinterleave_rows_device(flat.data_ptr() + 4, 8, 32, 2, 8, 16, 4, out.data_ptr())
+    torch.cuda.synchronize()
+    ref = np.empty((32, 8), np.int32)
+    s = src.cpu().numpy()
+    for r in range(32):
+        blk_i, j = divmod(r, 8)
+        ref[r] = s[blk_i % 2, (blk_i // 2) * 8 + j]
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_multi_one_device_mandelbrot_through_the_count_exchange(B, O):
+    """mc_multi_* with one device takes the same exchange path (counts -> colour table): bit-identical to the oracle's plane."""
+    with B.Multi(1) as m:
+        p = B.mandelbrot_params(77, 45, max_iter=200)
+        rgba, it = m.mandelbrot(p)
+        ref = O.mandelbrot_iters(77, 45, 200)
+        lut, _ = O.mandel_lut(200)
+        assert np.array_equal(it, ref) and np.array_equal(bits(rgba), bits(lut[ref]))
+
+
+@pytest.mark.skipif("n_devices() < 2", reason="needs two GPUs")
+def test_multi_two_devices_equal_single(ctx, B):
+    with B.Multi(2) as m:
+        p = B.mandelbrot_params(333, 170, max_iter=400)
+        rgba, it = m.mandelbrot(p)
+        r1, i1 = ctx.mandelbrot(p)
+        assert np.array_equal(it, i1) and np.array_equal(bits(rgba), bits(r1))
+        for mode in (B.PT_MATH_STRICT, B.PT_MATH_FAST):
+            q = B.pathtrace_params(90, 60, 24, math_mode=mode)
+            assert np.array_equal(bits(m.pathtrace(q)), bits(ctx.pathtrace(q))), mode
+
+
+@pytest.mark.skipif("n_devices() < 2", reason="needs two GPUs")
+@pytest.mark.parametrize("extra", [["--spp", "16"], ["--config", "K4", "--width", "768", "--height", "520"]])
+def test_bench_two_gpus_rccl_verify(extra):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--verify"] + extra
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["config"]["backend"] == "nccl" and d["config"]["verified_equal_to_single_gpu"] is True
+    assert d["config"]["gather_bytes_per_rank"] > 0

@@ -18,6 +18,7 @@ MC_OK = 0
 PRECISION_F32, PRECISION_DS = 0, 1
 PT_MATH_STRICT, PT_MATH_FAST = 0, 1
 MANDEL_FMA = 1
+MANDEL_ITERS_U16 = 2   # device form: d_iters is a uint16 plane (max_iter <= 65535): the multi-GPU exchange format
 PT_GENERIC_KERNEL = 1
 PT_KERNEL_REGROUP = 2   # diagnostic library only (lib/libmc_compute_regroup.so)
 PT_NO_BOX_KERNEL = 4    # fast math: the general slab kernel instead of the closed-box ones
@@ -89,6 +90,7 @@ def lib():
         L.mc_tile_rows.argtypes = [u32, u32, u32, u32]
         L.mc_tile_rows.restype = u32
         L.mc_deinterleave_rows_device_async.argtypes = [vp, vp, u32, u32, u32, u32, u32, u32, vp, vp]
+        L.mc_mandelbrot_assemble_device_async.argtypes = [vp, vp, vp, u32, u32, u32, u32, vp, vp, vp]
         L.mc_mandelbrot_default_params.argtypes = [u32, u32, C.POINTER(MandelbrotParams)]
         L.mc_mandelbrot_render.argtypes = [vp, C.POINTER(MandelbrotParams), vp, vp]
         L.mc_mandelbrot_render_device_async.argtypes = [vp, C.POINTER(MandelbrotParams), vp, vp, vp]
@@ -274,6 +276,13 @@ class Context:
     def convert_rgba8_device(self, d_rgba_f32, W, H, scale, rotate180, d_rgba8, stream=0):
         _check(lib().mc_convert_rgba8_device_async(self._h, d_rgba_f32, W, H, scale, int(rotate180), d_rgba8, stream or None),
                "mc_convert_rgba8_device_async")
+
+    def mandelbrot_assemble_device(self, p, d_tiles, iters_bytes, n_tiles, row_block, tile_rows_padded, d_rgba=0, d_iters=0, stream=0):
+        """Root side of the Mandelbrot exchange: gathered interleaved tiles of iteration counts (2 or 4 B/pixel) -> the whole
+        image's vec4 storage buffer (lut[n]) and / or its uint32 count plane."""
+        _check(lib().mc_mandelbrot_assemble_device_async(self._h, C.byref(p), d_tiles, iters_bytes, n_tiles, row_block,
+                                                         tile_rows_padded, d_rgba or None, d_iters or None, stream or None),
+               "mc_mandelbrot_assemble_device_async")
 
     def deinterleave_rows_device(self, d_tiles, W, H, n_tiles, row_block, tile_rows_padded, bpp, d_out, stream=0):
         _check(lib().mc_deinterleave_rows_device_async(self._h, d_tiles, W, H, n_tiles, row_block, tile_rows_padded, bpp,

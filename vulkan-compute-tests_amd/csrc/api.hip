@@ -316,6 +316,15 @@ int mc_deinterleave_rows_device_async(mc_context* ctx, const void* d_tiles, uint
                                     d_out, pick_stream(ctx, stream));
 }
 
+int mc_mandelbrot_assemble_device_async(mc_context* ctx, const mc_mandelbrot_params* p, const void* d_tiles, uint32_t iters_bytes,
+                                        uint32_t n_tiles, uint32_t row_block, uint32_t tile_rows_padded, void* d_rgba_f32,
+                                        void* d_iters, void* stream) {
+    if (!ctx) return MC_ERR_INVALID_ARGUMENT;
+    MC_HIP_TRY(hipSetDevice(ctx->device));
+    return mandelbrot_assemble_launch(ctx, p, d_tiles, iters_bytes, n_tiles, row_block, tile_rows_padded, d_rgba_f32, d_iters,
+                                      pick_stream(ctx, stream));
+}
+
 // ---- Mandelbrot -------------------------------------------------------------------------------------
 int mc_mandelbrot_default_params(uint32_t width, uint32_t height, mc_mandelbrot_params* p) {
     if (!p) return MC_ERR_INVALID_ARGUMENT;

@@ -36,6 +36,7 @@ struct MandelArgs {
     float sx_hi, sx_lo, sy_hi, sy_lo;
     float4* __restrict__ out_rgba;      // tile-local, may be null
     uint32_t* __restrict__ out_iters;   // tile-local, may be null
+    uint16_t* __restrict__ out_iters16; // the same plane as 16-bit counts (MC_MANDEL_ITERS_U16, max_iter <= 65535), may be null
     const float4* __restrict__ lut;     // max_iter+1 entries (null when out_rgba is null)
     // c = centre + (uv - 0.5) * scale per column / per row, evaluated once on the host with the shader's fp32
     // operation sequence (mandelbrot.comp:30-31,38): fp32 [cx[W] | cy[H]], two-float [cx(hi,lo)[W] | cy(hi,lo)[H]].
@@ -228,6 +229,7 @@ __global__ void __launch_bounds__(64) mandelbrot_kernel(MandelArgs a) {
     if (valid) {
         size_t idx = (size_t)ty * a.W + gx;                                    // :59 (row-major, tile-local)
         if (a.out_iters) a.out_iters[idx] = n;
+        if (a.out_iters16) a.out_iters16[idx] = (uint16_t)n;
         if (a.out_rgba) a.out_rgba[idx] = a.lut[n];
     }
 }
@@ -303,6 +305,14 @@ static int ensure_c_table(mc_context* ctx, const mc_mandelbrot_params* p, hipStr
     return MC_OK;
 }
 
+// The device colour table of (max_iter, k_color), uploaded on first use (mandelbrot_assemble_launch, postprocess.hip).
+int mandelbrot_lut_device(mc_context* ctx, const mc_mandelbrot_params* p, hipStream_t s, const void** d_lut) {
+    int rc = ensure_lut(ctx, p, s);
+    if (rc) return rc;
+    *d_lut = ctx->lut.ptr;
+    return MC_OK;
+}
+
 int mandelbrot_launch(mc_context* ctx, const mc_mandelbrot_params* p, void* d_rgba, void* d_iters, hipStream_t s) {
     if (!ctx || !p || (!d_rgba && !d_iters)) return MC_ERR_INVALID_ARGUMENT;
     if (!p->width || !p->height || !p->max_iter || p->row_end > p->height || p->row_begin >= p->row_end)
@@ -325,7 +335,10 @@ int mandelbrot_launch(mc_context* ctx, const mc_mandelbrot_params* p, void* d_rg
     a.cx_hi = p->centre_x_hi; a.cx_lo = p->centre_x_lo; a.cy_hi = p->centre_y_hi; a.cy_lo = p->centre_y_lo;
     a.sx_hi = p->scale_x_hi; a.sx_lo = p->scale_x_lo; a.sy_hi = p->scale_y_hi; a.sy_lo = p->scale_y_lo;
     a.out_rgba = (float4*)d_rgba;
-    a.out_iters = (uint32_t*)d_iters;
+    const bool narrow = (p->flags & MC_MANDEL_ITERS_U16) != 0u;
+    if (narrow && p->max_iter > 65535u) return MC_ERR_INVALID_ARGUMENT;
+    a.out_iters = narrow ? nullptr : (uint32_t*)d_iters;
+    a.out_iters16 = narrow ? (uint16_t*)d_iters : nullptr;
     a.lut = d_rgba ? (const float4*)ctx->lut.ptr : nullptr;
     const uint32_t rows = tile_rows(p->row_begin, p->row_end, a.row_block, a.row_stride);
     dim3 grid((p->width + 7u) / 8u, (rows + 7u) / 8u), block(64);

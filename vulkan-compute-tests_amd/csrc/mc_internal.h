@@ -66,6 +66,7 @@ namespace mc {
 // mandelbrot.hip
 int mandelbrot_launch(mc_context* ctx, const mc_mandelbrot_params* p, void* d_rgba, void* d_iters, hipStream_t s);
 void mandelbrot_build_lut(uint32_t max_iter, const float k_color[4], float* lut);
+int mandelbrot_lut_device(mc_context* ctx, const mc_mandelbrot_params* p, hipStream_t s, const void** d_lut);
 // pathtrace.hip
 uint32_t pathtrace_scene_class(const float* planes, uint32_t n_planes, const float* spheres, uint32_t n_spheres);
 int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
@@ -75,6 +76,8 @@ int convert_rgba8_launch(mc_context* ctx, const void* d_rgba_f32, uint32_t W, ui
                          void* d_rgba8, hipStream_t s);
 int deinterleave_rows_launch(mc_context* ctx, const void* d_tiles, uint32_t W, uint32_t H, uint32_t n_tiles, uint32_t B,
                              uint32_t tile_rows_padded, uint32_t bytes_per_pixel, void* d_out, hipStream_t s);
+int mandelbrot_assemble_launch(mc_context* ctx, const mc_mandelbrot_params* p, const void* d_tiles, uint32_t iters_bytes,
+                               uint32_t n_tiles, uint32_t B, uint32_t tile_rows_padded, void* d_rgba, void* d_iters, hipStream_t s);
 
 // Interleaved row-block tiling (include/mc_compute.h: row_block,row_stride).  Tile-local row ty maps to
 // storage row row_begin + (ty / B) * stride + ty % B; B == 0 means contiguous.

@@ -7,8 +7,9 @@
 // same bits as the single-GPU run: N-GPU output must memcmp-equal the 1-GPU output.  Samples are
 // never split across GPUs (the fp32 accumulation order is part of the contract).
 //
-// A gather to one root on the fully connected 8-GPU xGMI mesh uses the root's 7 inbound links
-// concurrently; tiles are 20-80 MB/rank, i.e. well under a millisecond next to >=100 ms renders.
+// A gather to one root on the fully connected 8-GPU xGMI mesh uses the root's 7 inbound links concurrently.  The path tracer
+// exchanges its fp32 tiles (K3: 19.7 MB per rank next to 0.3 s of render); the Mandelbrot exchanges iteration counts only —
+// 2 B/pixel — and device 0 rebuilds the vec4 buffer from them (K4: 9.8 MB per rank next to 7 ms of render).
 #include <rccl/rccl.h>
 
 #include <cstdlib>
@@ -36,15 +37,12 @@ namespace mc {
         }                                                                                       \
     } while (0)
 
-// Gathers equal-sized tiles (count elements of `type` per rank) to device 0 and de-interleaves them.
-static int gather_and_assemble(mc_multi* m, std::vector<DeviceBuffer>& tiles, DeviceBuffer& gathered, DeviceBuffer& full,
-                               uint32_t W, uint32_t H, uint32_t tile_rows_padded, uint32_t bpp) {
-    const size_t tile_bytes = (size_t)tile_rows_padded * W * bpp;
+// Gathers equal-sized tiles (tile_bytes per rank) to device 0: `gathered` holds them back to back in rank order.
+static int gather_tiles(mc_multi* m, std::vector<DeviceBuffer>& tiles, DeviceBuffer& gathered, size_t tile_bytes) {
     mc_context* c0 = m->ctx[0];
     MC_HIP_TRY(hipSetDevice(c0->device));
     int rc;
     if ((rc = gathered.reserve(tile_bytes * m->n))) return rc;
-    if ((rc = full.reserve((size_t)W * H * bpp))) return rc;
     if (m->use_rccl) {
         MC_NCCL_TRY(ncclGroupStart());
         for (int i = 0; i < m->n; i++) {
@@ -69,6 +67,16 @@ static int gather_and_assemble(mc_multi* m, std::vector<DeviceBuffer>& tiles, De
         MC_HIP_TRY(hipMemcpyAsync(gathered.ptr, tiles[0].ptr, tile_bytes, hipMemcpyDeviceToDevice, c0->stream));
     }
     MC_HIP_TRY(hipSetDevice(c0->device));
+    return MC_OK;
+}
+
+// Gathers the tiles of a bpp-byte-per-pixel plane to device 0 and de-interleaves them into `full`.
+static int gather_and_assemble(mc_multi* m, std::vector<DeviceBuffer>& tiles, DeviceBuffer& gathered, DeviceBuffer& full,
+                               uint32_t W, uint32_t H, uint32_t tile_rows_padded, uint32_t bpp) {
+    int rc;
+    if ((rc = gather_tiles(m, tiles, gathered, (size_t)tile_rows_padded * W * bpp))) return rc;
+    mc_context* c0 = m->ctx[0];
+    if ((rc = full.reserve((size_t)W * H * bpp))) return rc;
     if (m->n == 1) {   // one tile = the image in storage order already: no row shuffle, any width
         MC_HIP_TRY(hipMemcpyAsync(full.ptr, gathered.ptr, (size_t)W * H * bpp, hipMemcpyDeviceToDevice, c0->stream));
         return MC_OK;
@@ -151,35 +159,40 @@ static int multi_mandelbrot(mc_multi* m, const mc_mandelbrot_params* p, float* o
     if (p->row_begin != 0 || p->row_end != p->height || p->row_stride) return MC_ERR_INVALID_ARGUMENT;   // whole image only
     const uint32_t W = p->width, H = p->height;
     const uint32_t padded = padded_tile_rows(H, m->n);
+    // The exchange carries ITERATION COUNTS — 2 B/pixel (max_iter <= 65535) or 4 — never the 16-B vec4: the colour is a function
+    // of the count alone (mandelbrot.comp:50-59), so device 0 rebuilds the storage buffer from the gathered counts through the
+    // same table the render kernel reads.  K4 on 8 GPUs: 9.8 MB per rank instead of 78.6 MB.
+    const bool narrow = p->max_iter <= 65535u;
+    const uint32_t ib = narrow ? 2u : 4u;
     int rc;
     for (int i = 0; i < m->n; i++) {
         mc_context* c = m->ctx[i];
         MC_HIP_TRY(hipSetDevice(c->device));
-        if (want_rgba && (rc = m->tile_rgba[i].reserve((size_t)padded * W * 16))) return rc;
-        if (out_iters && (rc = m->tile_iters[i].reserve((size_t)padded * W * 4))) return rc;
+        if ((rc = m->tile_iters[i].reserve((size_t)padded * W * ib))) return rc;
         mc_mandelbrot_params q = *p;
         q.row_begin = (uint32_t)i * kRowBlock; q.row_end = H;
         q.row_block = kRowBlock; q.row_stride = kRowBlock * (uint32_t)m->n;
+        q.flags = narrow ? (p->flags | MC_MANDEL_ITERS_U16) : (p->flags & ~(uint32_t)MC_MANDEL_ITERS_U16);
         if (q.row_begin >= H) continue;   // more GPUs than row blocks
-        rc = mandelbrot_launch(c, &q, want_rgba ? m->tile_rgba[i].ptr : nullptr, out_iters ? m->tile_iters[i].ptr : nullptr,
-                               c->stream);
+        rc = mandelbrot_launch(c, &q, nullptr, m->tile_iters[i].ptr, c->stream);
         if (rc) return rc;
     }
     mc_context* c0 = m->ctx[0];
-    if (want_rgba) {
-        if ((rc = gather_and_assemble(m, m->tile_rgba, m->gather_rgba, m->full_rgba, W, H, padded, 16))) return rc;
-        if (out_rgba_f32)
-            MC_HIP_TRY(hipMemcpyAsync(out_rgba_f32, m->full_rgba.ptr, (size_t)W * H * 16, hipMemcpyDeviceToHost, c0->stream));
-        if (out_rgba8) {   // mandelbrotApp.h:159-174 on device 0: only 4 B/pixel leave the GPU
-            if ((rc = m->full_u8.reserve((size_t)W * H * 4))) return rc;
-            if ((rc = convert_rgba8_launch(c0, m->full_rgba.ptr, W, H, 255.0f, 0, m->full_u8.ptr, c0->stream))) return rc;
-            MC_HIP_TRY(hipMemcpyAsync(out_rgba8, m->full_u8.ptr, (size_t)W * H * 4, hipMemcpyDeviceToHost, c0->stream));
-        }
+    if ((rc = gather_tiles(m, m->tile_iters, m->gather_iters, (size_t)padded * W * ib))) return rc;
+    if (want_rgba && (rc = m->full_rgba.reserve((size_t)W * H * 16))) return rc;
+    if (out_iters && (rc = m->full_iters.reserve((size_t)W * H * 4))) return rc;
+    if ((rc = mandelbrot_assemble_launch(c0, p, m->gather_iters.ptr, ib, (uint32_t)m->n, kRowBlock, padded,
+                                         want_rgba ? m->full_rgba.ptr : nullptr, out_iters ? m->full_iters.ptr : nullptr, c0->stream)))
+        return rc;
+    if (out_rgba_f32)
+        MC_HIP_TRY(hipMemcpyAsync(out_rgba_f32, m->full_rgba.ptr, (size_t)W * H * 16, hipMemcpyDeviceToHost, c0->stream));
+    if (out_rgba8) {   // mandelbrotApp.h:159-174 on device 0: only 4 B/pixel leave the GPU
+        if ((rc = m->full_u8.reserve((size_t)W * H * 4))) return rc;
+        if ((rc = convert_rgba8_launch(c0, m->full_rgba.ptr, W, H, 255.0f, 0, m->full_u8.ptr, c0->stream))) return rc;
+        MC_HIP_TRY(hipMemcpyAsync(out_rgba8, m->full_u8.ptr, (size_t)W * H * 4, hipMemcpyDeviceToHost, c0->stream));
     }
-    if (out_iters) {
-        if ((rc = gather_and_assemble(m, m->tile_iters, m->gather_iters, m->full_iters, W, H, padded, 4))) return rc;
+    if (out_iters)
         MC_HIP_TRY(hipMemcpyAsync(out_iters, m->full_iters.ptr, (size_t)W * H * 4, hipMemcpyDeviceToHost, c0->stream));
-    }
     for (int i = 0; i < m->n; i++) {
         MC_HIP_TRY(hipSetDevice(m->ctx[i]->device));
         MC_HIP_TRY(hipStreamSynchronize(m->ctx[i]->stream));

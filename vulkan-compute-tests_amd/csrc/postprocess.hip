@@ -56,14 +56,64 @@ __global__ void __launch_bounds__(256) deinterleave_rows_kernel(const G* __restr
     }
 }
 
+// Mandelbrot exchange on the root (multi-GPU): the ranks send their ITERATION COUNTS (2 or 4 B/pixel instead of the 16-B vec4),
+// and the root rebuilds the storage buffer in one pass — de-interleave the tiles as above and write lut[n], the very vec4 the
+// render kernel writes for that count (mandelbrot.comp:50-59: the colour is a function of n alone).  2-4 B read + 16 B
+// (+ 4 B for the optional count plane) written per pixel: HBM-bound.
+template <class T>
+__global__ void __launch_bounds__(256) mandelbrot_assemble_kernel(const T* __restrict__ tiles, const float4* __restrict__ lut,
+                                                                  float4* __restrict__ rgba, uint32_t* __restrict__ iters, uint32_t W,
+                                                                  uint32_t H, uint32_t max_iter, uint32_t n_tiles, uint32_t B,
+                                                                  uint32_t tile_rows_padded) {
+    const size_t total = (size_t)W * H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t r = (uint32_t)(i / W), x = (uint32_t)(i - (size_t)r * W);
+        const uint32_t blk = r / B, j = r - blk * B;
+        const uint32_t t = blk % n_tiles, k = blk / n_tiles;
+        uint32_t n = (uint32_t)tiles[((size_t)t * tile_rows_padded + (size_t)k * B + j) * W + x];
+        if (n > max_iter) n = max_iter;   // (never: the counts come from the render kernel; keeps the table read in range)
+        if (rgba) rgba[i] = lut[n];
+        if (iters) iters[i] = n;
+    }
+}
+
 }  // namespace
+
+int mandelbrot_assemble_launch(mc_context* ctx, const mc_mandelbrot_params* p, const void* d_tiles, uint32_t iters_bytes,
+                               uint32_t n_tiles, uint32_t B, uint32_t tile_rows_padded, void* d_rgba, void* d_iters, hipStream_t s) {
+    if (!ctx || !p || !d_tiles || (!d_rgba && !d_iters) || !p->width || !p->height || !p->max_iter || !n_tiles || !B)
+        return MC_ERR_INVALID_ARGUMENT;
+    if (iters_bytes != 2u && iters_bytes != 4u) return MC_ERR_INVALID_ARGUMENT;
+    if (iters_bytes == 2u && p->max_iter > 65535u) return MC_ERR_INVALID_ARGUMENT;
+    const void* d_lut = nullptr;
+    if (d_rgba) {
+        int rc = mandelbrot_lut_device(ctx, p, s, &d_lut);
+        if (rc) return rc;
+    }
+    const size_t total = (size_t)p->width * p->height;
+    uint32_t blocks = (uint32_t)((total + 255) / 256);
+    const uint32_t cap = (uint32_t)ctx->props.multiProcessorCount * 8u;
+    if (blocks > cap) blocks = cap;
+    if (iters_bytes == 2u)
+        hipLaunchKernelGGL(mandelbrot_assemble_kernel<uint16_t>, dim3(blocks), dim3(256), 0, s, (const uint16_t*)d_tiles,
+                           (const float4*)d_lut, (float4*)d_rgba, (uint32_t*)d_iters, p->width, p->height, p->max_iter, n_tiles, B,
+                           tile_rows_padded);
+    else
+        hipLaunchKernelGGL(mandelbrot_assemble_kernel<uint32_t>, dim3(blocks), dim3(256), 0, s, (const uint32_t*)d_tiles,
+                           (const float4*)d_lut, (float4*)d_rgba, (uint32_t*)d_iters, p->width, p->height, p->max_iter, n_tiles, B,
+                           tile_rows_padded);
+    MC_HIP_TRY(hipGetLastError());
+    return d_rgba ? ctx->note_launch(s) : MC_OK;   // (reads the cached colour table)
+}
 
 int deinterleave_rows_launch(mc_context* ctx, const void* d_tiles, uint32_t W, uint32_t H, uint32_t n_tiles, uint32_t B,
                              uint32_t tile_rows_padded, uint32_t bytes_per_pixel, void* d_out, hipStream_t s) {
     if (!ctx || !d_tiles || !d_out || !W || !H || !n_tiles || !B) return MC_ERR_INVALID_ARGUMENT;
     size_t row_bytes = (size_t)W * bytes_per_pixel;
     if (bytes_per_pixel != 16 && bytes_per_pixel != 4) return MC_ERR_INVALID_ARGUMENT;
-    const bool wide = (row_bytes % 16) == 0;   // hipMalloc'ed tiles are 256-B aligned, so every row then starts on a 16-B boundary
+    // 16-B granules need 16-B row starts: a row length that is a multiple of 16 B AND 16-B aligned bases (a caller may pass a
+    // sliced or offset device pointer); anything else takes the 4-B granule kernel
+    const bool wide = (row_bytes % 16) == 0 && ((reinterpret_cast<uintptr_t>(d_tiles) | reinterpret_cast<uintptr_t>(d_out)) % 16) == 0;
     uint32_t row_granules = (uint32_t)(row_bytes / (wide ? 16 : 4));
     size_t total = (size_t)row_granules * H;
     uint32_t blocks = (uint32_t)((total + 255) / 256);

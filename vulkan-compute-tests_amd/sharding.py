@@ -3,8 +3,10 @@
 The path shards with NO data-path collective during the render: every pixel is independent and keyed by its
 absolute coordinates (pathTracer.comp:357,393; mandelbrot.comp:30-38), so rank r renders the interleaved
 ROW_BLOCK-row blocks r, r+n, r+2n, ... of the storage buffer with the GLOBAL (W, H) and gets the same bits as a
-single-GPU render.  One exchange step follows: the fp32 tiles are gathered to rank 0 (RCCL over xGMI when the
-backend is "nccl"), which re-assembles the storage buffer with mc_deinterleave_rows_device_async.
+single-GPU render.  One exchange step follows: the tiles are gathered to rank 0 (RCCL over xGMI when the backend is "nccl")
+— the path tracer's fp32 vec4 tiles, re-assembled with mc_deinterleave_rows_device_async; for the Mandelbrot only the
+iteration counts (uint16 for max_iter <= 65535: 2 B/pixel instead of 16), from which rank 0 rebuilds the vec4 buffer through the
+colour table (mc_mandelbrot_assemble_device_async: the colour is a function of the count alone, mandelbrot.comp:50-59).
 Samples are never split across ranks: the fp32 accumulation order is part of the parity contract.
 """
 import torch
@@ -55,6 +57,77 @@ def gather_tiles(tile, rank, n, dst=0):
     return torch.stack(bufs) if rank == dst else None
 
 
+class Exchange:
+    """The exchange step of a multi-rank render, shaped for a loop of steps: receive buffers allocated ONCE (the gather
+    writes straight into views of one (n, rows_padded, W, ...) tensor — no per-step allocation, no torch.stack), two
+    tile / receive buffer sets used alternately, and the gather issued asynchronously so that step i's exchange and rank 0's
+    re-assembly (on a side stream) overlap step i + 1's render.  `assemble(recv, stream_handle)` runs on rank 0's side stream.
+    (16-bit iteration counts travel as a uint8 tensor with a trailing dimension of 2: RCCL has no 16-bit integer type.)
+
+      ex = Exchange(rank, n, tile_shape, dtype, device)
+      for i in steps:  tile = ex.tile(i);  render into tile;  ex.submit(i, assemble)      # returns at once
+      ex.finish()                                                                          # before reading `out` / timing
+
+    RCCL (backend "nccl"): dist.gather(async_op=True) runs on the process group's own stream after the render stream's work
+    queued so far; Work.wait() makes the CURRENT stream wait for it, so it is called under the side stream.  gloo
+    (rehearsal, ranks sharing a GPU): the tile is staged through the host and the call is synchronous."""
+
+    def __init__(self, rank, n, tile_shape, dtype, device, dst=0):
+        self.rank, self.n, self.dst = rank, n, dst
+        self.gloo = n > 1 and dist.get_backend() == "gloo"
+        self.tiles = [torch.zeros(tile_shape, dtype=dtype, device=device) for _ in range(2 if n > 1 else 1)]
+        self.recv = ([torch.empty((n,) + tuple(tile_shape), dtype=dtype, device=device) for _ in range(2)]
+                     if n > 1 and rank == dst else None)
+        self.side = torch.cuda.Stream(device=device) if (n > 1 and torch.device(device).type == "cuda") else None
+        self.pending = [None, None]
+        self.bytes_per_rank = self.tiles[0].numel() * self.tiles[0].element_size()
+
+    def tile(self, i):
+        """The tile buffer of step i.  The render stream is made to wait (on the device, not the host) for the exchange that
+        last used this buffer set, two steps ago: its gather read the tile, its re-assembly read the receive buffer."""
+        k = i % len(self.tiles)
+        if self.pending[k] is not None:
+            torch.cuda.current_stream().wait_event(self.pending[k])
+            self.pending[k] = None
+        return self.tiles[k]
+
+    def submit(self, i, assemble=None, done_event=None):
+        if self.n == 1:
+            return
+        k = i % 2
+        tile = self.tiles[k]
+        if self.gloo:
+            host = tile.cpu()
+            bufs = list(torch.empty((self.n,) + tuple(host.shape), dtype=host.dtype).unbind(0)) if self.rank == self.dst else None
+            dist.gather(host, bufs, dst=self.dst)
+            if self.rank == self.dst:
+                self.recv[k].copy_(torch.stack(bufs))
+                if assemble is not None:
+                    assemble(self.recv[k], torch.cuda.current_stream().cuda_stream)
+            if done_event is not None:
+                done_event.record()
+            return
+        bufs = list(self.recv[k].unbind(0)) if self.rank == self.dst else None
+        work = dist.gather(tile, bufs, dst=self.dst, async_op=True)
+        ev = torch.cuda.Event()
+        with torch.cuda.stream(self.side):
+            work.wait()                         # the side stream waits for the collective; the render stream does not
+            if self.rank == self.dst and assemble is not None:
+                assemble(self.recv[k], self.side.cuda_stream)
+            ev.record()
+            if done_event is not None:
+                done_event.record()
+        self.pending[k] = ev
+
+    def finish(self):
+        for k in range(2):
+            if self.pending[k] is not None:
+                self.pending[k].synchronize()
+                self.pending[k] = None
+        if self.side is not None:
+            self.side.synchronize()
+
+
 def assemble_device(ctx, gathered, width, height, n, out, stream=0, block=ROW_BLOCK):
     """Rank 0, on the GPU: gathered (n, rows_padded, W, C) -> out (H, W, C) in storage-row order."""
     if not gathered.is_cuda or not out.is_cuda:
@@ -62,3 +135,15 @@ def assemble_device(ctx, gathered, width, height, n, out, stream=0, block=ROW_BL
     bpp = gathered.element_size() * gathered.shape[-1] if gathered.dim() == 4 else gathered.element_size()
     ctx.deinterleave_rows_device(gathered.data_ptr(), width, height, n, block, gathered.shape[1], bpp, out.data_ptr(), stream)
     return out
+
+
+def assemble_mandelbrot_device(ctx, p, gathered, n, out_rgba, out_iters=None, stream=0, block=ROW_BLOCK):
+    """Rank 0, on the GPU: gathered (n, rows_padded, W) int32 iteration counts — or (n, rows_padded, W, 2) uint8 holding 16-bit
+    counts — -> the vec4 storage buffer out_rgba (H, W, 4) through the colour table, and optionally the int32 count plane."""
+    if not gathered.is_cuda:
+        raise RuntimeError("assemble_mandelbrot_device needs device tensors (there is no CPU path in the product)")
+    iters_bytes = 2 if gathered.dim() == 4 else gathered.element_size()
+    ctx.mandelbrot_assemble_device(p, gathered.data_ptr(), iters_bytes, n, block, gathered.shape[1],
+                                   out_rgba.data_ptr() if out_rgba is not None else 0,
+                                   out_iters.data_ptr() if out_iters is not None else 0, stream)
+    return out_rgba
