@@ -391,7 +391,9 @@ def main():
                        "tiling": "whole image" if n == 1 else f"interleaved {ROW_BLOCK}-row blocks, RCCL gather to rank 0",
                        **({"exchange": ("fp32 vec4 tiles (16 B/pixel)" if is_pt else
                                         ("uint16" if narrow else "uint32") + " iteration counts; rank 0 rebuilds the vec4 buffer through the colour table") +
-                                       "; asynchronous gather + re-assembly on a side stream, overlapping the next step's render"} if n > 1 else {}),
+                                       ("; synchronous gather on the render stream" if ex.sync_mode or backend != "nccl" else
+                                        "; asynchronous gather + re-assembly on a side stream, overlapping the next step's render")}
+                          if n > 1 else {}),
                        "device": dev_name, "compute_units": cus, "sclk_mhz_under_valu_load": round(sclk_mhz, 1),
                        **({"unit_note": "reference-equivalent pixel-iterations (see roofline.lane_ops.note)"} if not is_pt else {}),
                        **({"backend": backend, "world_size": dist.get_world_size(), "ranks": ranks_info,

@@ -9,6 +9,9 @@ iteration counts (uint16 for max_iter <= 65535: 2 B/pixel instead of 16), from w
 colour table (mc_mandelbrot_assemble_device_async: the colour is a function of the count alone, mandelbrot.comp:50-59).
 Samples are never split across ranks: the fp32 accumulation order is part of the parity contract.
 """
+import os
+import sys
+
 import torch
 import torch.distributed as dist
 
@@ -81,6 +84,9 @@ class Exchange:
         self.side = torch.cuda.Stream(device=device) if (n > 1 and torch.device(device).type == "cuda") else None
         self.pending = [None, None]
         self.bytes_per_rank = self.tiles[0].numel() * self.tiles[0].element_size()
+        # MC_BENCH_SYNC_EXCHANGE=1 (or an exception from the asynchronous path, reported on stderr): the same collective issued
+        # synchronously on the render stream — no overlap, same bytes, same result.  Which one ran is reported by bench.py.
+        self.sync_mode = os.environ.get("MC_BENCH_SYNC_EXCHANGE", "0") == "1"
 
     def tile(self, i):
         """The tile buffer of step i.  The render stream is made to wait (on the device, not the host) for the exchange that
@@ -108,16 +114,36 @@ class Exchange:
                 done_event.record()
             return
         bufs = list(self.recv[k].unbind(0)) if self.rank == self.dst else None
-        work = dist.gather(tile, bufs, dst=self.dst, async_op=True)
-        ev = torch.cuda.Event()
-        with torch.cuda.stream(self.side):
-            work.wait()                         # the side stream waits for the collective; the render stream does not
-            if self.rank == self.dst and assemble is not None:
-                assemble(self.recv[k], self.side.cuda_stream)
-            ev.record()
-            if done_event is not None:
-                done_event.record()
-        self.pending[k] = ev
+        if not self.sync_mode:
+            work = None
+            try:
+                work = dist.gather(tile, bufs, dst=self.dst, async_op=True)
+                ev = torch.cuda.Event()
+                with torch.cuda.stream(self.side):
+                    work.wait()                 # the side stream waits for the collective; the render stream does not
+                    if self.rank == self.dst and assemble is not None:
+                        assemble(self.recv[k], self.side.cuda_stream)
+                    ev.record()
+                    if done_event is not None:
+                        done_event.record()
+                self.pending[k] = ev
+                return
+            except Exception as e:              # noqa: BLE001 — keep the job alive: the exchange is correct either way
+                print(f"[sharding.Exchange] asynchronous exchange failed on rank {self.rank} ({e!r}); continuing synchronously",
+                      file=sys.stderr, flush=True)
+                self.sync_mode = True
+                if work is not None:            # the collective was issued: complete it on the render stream
+                    work.wait()
+                    if self.rank == self.dst and assemble is not None:
+                        assemble(self.recv[k], torch.cuda.current_stream().cuda_stream)
+                    if done_event is not None:
+                        done_event.record()
+                    return
+        dist.gather(tile, bufs, dst=self.dst)
+        if self.rank == self.dst and assemble is not None:
+            assemble(self.recv[k], torch.cuda.current_stream().cuda_stream)
+        if done_event is not None:
+            done_event.record()
 
     def finish(self):
         for k in range(2):
