@@ -63,7 +63,7 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "liboracle.so")
+        path = os.environ.get("MC_ORACLE_LIB_PATH") or os.path.join(_HERE, "liboracle.so")   # (sanitizer build: oracle/_san/)
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)

@@ -97,7 +97,7 @@ def test_error_strings_and_argument_validation_without_gpu(B):
 # ---- host helpers -------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def hostutil(B):
-    path = os.path.join(os.path.dirname(B.LIB_PATH), "libmc_hostutil.so")
+    path = os.environ.get("MC_HOSTUTIL_LIB_PATH") or os.path.join(os.path.dirname(B.LIB_PATH), "libmc_hostutil.so")
     H = C.CDLL(path)
     H.mcu_png_encode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_size_t)]
     H.mcu_free.argtypes = [C.c_void_p]

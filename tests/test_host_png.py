@@ -12,7 +12,7 @@ import pytest
 
 @pytest.fixture(scope="module")
 def H(B):
-    lib = C.CDLL(os.path.join(os.path.dirname(B.LIB_PATH), "libmc_hostutil.so"))
+    lib = C.CDLL(os.environ.get("MC_HOSTUTIL_LIB_PATH") or os.path.join(os.path.dirname(B.LIB_PATH), "libmc_hostutil.so"))
     lib.mcu_png_encode_mt.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_size_t)]
     lib.mcu_free.argtypes = [C.c_void_p]
     return lib
