@@ -10,7 +10,7 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(pathtrace_kernel<[^>]*>|pathtrace_regroup_kernel<[^>]*>|mandelbrot_kernel<.*?, \d+>|convert_rgba8_kernel|deinterleave_rows_kernel)", name)
+    m = re.search(r"(pathtrace_kernel<[^>]*>|pathtrace_pool_kernel<[^>]*>|pathtrace_regroup_kernel<[^>]*>|mandelbrot_kernel<.*?, \d+>|convert_rgba8_kernel|deinterleave_rows_kernel)", name)
     return m.group(1) if m else None
 
 
