@@ -3,7 +3,9 @@ keep the whole image's wave tiles).  Every sample's arithmetic is the round-sync
 order in which a pixel's fp32 contributions are added.  So: (1) against that kernel the storage buffer agrees to the last few
 ulps except where a rounding forks a path (different inlining contexts contract differently), (2) against the oracle it obeys
 the fast-math tolerance, (3) it is deterministic and tiling-invariant bit for bit, (4) everything outside its domain runs the
-round-synchronous kernels exactly as before."""
+round-synchronous kernels exactly as before.
+The STRICT pool kernel keeps a per-path accrad and adds accrad / spp in sample order through a result ring in LDS: it must be
+bit-identical to the oracle — and to the round-synchronous strict kernel — for every size, depth limit, sample count and tile."""
 import numpy as np
 import pytest
 
@@ -89,3 +91,30 @@ def test_pool_kernel_k3_band_at_4096_spp(ctx, B, O):
     p999 = float(np.percentile(np.sqrt((d ** 2).sum(-1)), 99.9))
     print(f"pool K3 band vs oracle(libm): rmse {rmse:.4f}  p99.9 L2 {p999:.3f}  mean diff {d.mean():+.5f}")
     assert rmse <= 0.5 and p999 <= 4.0 and abs(d.mean()) < 0.02
+
+
+@pytest.mark.parametrize("W,H,spp,depth", [(8, 8, 16, 12), (33, 9, 37, 12), (3, 5, 1, 12), (1, 1, 500, 12), (64, 48, 100, 12),
+                                           (40, 24, 70, 7), (40, 24, 33, 2), (40, 24, 20, 1), (20, 12, 9, 15), (16, 16, 600, 12)])
+def test_strict_pool_kernel_is_bit_identical_to_the_oracle(ctx, B, O, W, H, spp, depth):
+    """Sample counts around the batch (16) and result-ring (64) sizes, ragged last batches, one-sample pools, depth limits that
+    end every path at once — the ordered sum through the result ring must be the oracle's, bit for bit."""
+    ref = O.pathtrace(W, H, spp, math_mode=O.MATH_MC, max_depth=depth)
+    pool = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_STRICT, max_depth=depth))
+    assert np.array_equal(bits(pool), bits(ref))
+    rounds = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_STRICT, max_depth=depth, flags=B.PT_NO_POOL_KERNEL))
+    assert np.array_equal(bits(rounds), bits(ref))
+
+
+def test_strict_pool_kernel_tiles_of_any_alignment(ctx, B, O):
+    """Strict tiles need no alignment (the sum is in sample order whatever the wave holds): odd row ranges, interleaved blocks."""
+    W, H, spp = 40, 24, 19
+    whole = O.pathtrace(W, H, spp, math_mode=O.MATH_MC)
+    for (r0, r1) in [(5, 17), (0, 23), (7, 8)]:
+        t = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_STRICT, row_begin=r0, row_end=r1))
+        assert np.array_equal(bits(t), bits(whole[r0:r1])), (r0, r1)
+    blk, n = B.lib().mc_row_block(), 2
+    for rank in range(n):
+        t = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_STRICT, row_begin=rank * blk, row_end=H, row_block=blk,
+                                             row_stride=n * blk))
+        rows = np.array([r for r in range(H) if (r // blk) % n == rank])
+        assert np.array_equal(bits(t), bits(whole[rows])), rank

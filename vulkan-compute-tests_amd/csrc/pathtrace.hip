@@ -209,18 +209,20 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
     if (S != 1 && S != 4 && S != 16) return MC_ERR_INVALID_ARGUMENT;
     if (prec != 0 && S == 4) S = (p->sample_end - p->sample_begin) >= 16 ? 16 : 1;   // precision variants exist for S = 1, 16
     int variant = slab ? 1 : 0;
-    if (slab && p->math_mode == MC_PT_MATH_FAST && a.scene.box_ok && !(p->flags & MC_PT_NO_BOX_KERNEL)) {
-        variant = 3;
-        // The sample-pool kernel (pathtrace_pool.h): whole sample ranges only (its pixel sums are formed in LDS and scaled once),
-        // the automatic width, and tiles whose wave tiles are those of the whole image — a wave's pixels, hence its schedule
-        // and the order of its fp32 additions, are then the same for every tiling: N-GPU output == 1-GPU output, bit for bit.
-        // Its width is 16 lanes per pixel and batch (2 x 2 pixels per wave) for every image size — never a function of the tile.
+    if (slab && a.scene.box_ok && !(p->flags & MC_PT_NO_BOX_KERNEL)) {
+        const bool fast = p->math_mode == MC_PT_MATH_FAST;
+        if (fast) variant = 3;   // the closed-box round-synchronous kernels (scene facts at compile time)
+        // The sample-pool kernels (pathtrace_pool.h): whole sample ranges only (the pixel sums are formed inside the launch), the
+        // automatic width; 16 lanes per pixel and batch (2 x 2 pixels per wave) for every image size — never a function of the tile.
+        // Fast math adds a pixel's radiance in an order that depends on the wave's schedule, so it is selected only for tiles whose
+        // wave tiles are those of the whole image — a wave's pixels, hence its schedule, are then the same for every tiling:
+        // N-GPU output == 1-GPU output, bit for bit.  The strict variant adds in sample order whatever the tile.
         const uint32_t th = 2u;   // WaveTile<16>::h
         const bool whole_range = p->sample_begin == 0u && p->sample_end == p->spp;
         const bool aligned = p->row_begin % th == 0u && (a.row_block == 0u || (a.row_block % th == 0u && a.row_stride % th == 0u)) &&
                              (p->row_end % th == 0u || p->row_end == p->height);
         const bool fits = p->max_depth >= 1u && (uint64_t)p->spp * p->max_depth < (1ull << 32) && p->width < (1u << 24);
-        if (((p->flags >> 8) & 0xffu) == 0u && !(p->flags & MC_PT_NO_POOL_KERNEL) && whole_range && aligned && fits) variant = 4;
+        if (((p->flags >> 8) & 0xffu) == 0u && !(p->flags & MC_PT_NO_POOL_KERNEL) && whole_range && (aligned || !fast) && fits) variant = 4;
     }
     // Lane-regrouping scheduler (pathtrace_regroup.h): slab scenes whose materials are all 1..3 (any other code makes the
     // shader re-trace an unchanged ray, which only the round-synchronous loop reproduces) within its packed-field limits.

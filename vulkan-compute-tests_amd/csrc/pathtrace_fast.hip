@@ -35,7 +35,7 @@ int launch_fast(const PTArgs& a, int variant, int S, int prec, uint32_t tile_row
     if (variant == 2) return launch_regroup<true, 4>(a, tile_rows, s);
 #endif
     if (variant == 2) return MC_ERR_UNSUPPORTED;
-    if (variant == 4) return launch_pool(a, S, tile_rows, s);
+    if (variant == 4) return launch_pool<true>(a, S, tile_rows, s);
     return launch_impl<true>(a, variant, S, prec, tile_rows, s);
 }
 }  // namespace pt

@@ -628,6 +628,48 @@ __device__ __forceinline__ v3 specular_bounce_fast(int mat, v3 rd, v3 n, float d
     return rd * alpha + n * beta;
 }
 
+// Mirror / glass bounce in the general form (:432-:447) — the strict kernels (literal operation order) and the fast generic
+// kernel.  mat is 2 or 3; nl as :390; dot_n_rd = dot(n, rd) (fast only); rx = rnd.x; accmat receives :445's weight.
+template <bool Fast, bool Slab>
+__device__ __forceinline__ v3 specular_bounce_general(int mat, v3 rd, v3 n, v3 nl, float dot_n_rd, float rx, v3& accmat) {
+    MC_PT_DECISION_FP
+    const v3 refl = reflect(rd, n);
+    if (mat == 3) {
+        MC_REGION(6);   // glass
+        // fast: nl is n exactly when dot(n, rd) carries a sign bit, and dot(rd, nl) is then -|dot(n, rd)|
+        bool into = Fast ? (dm::as_uint(dot_n_rd) >> 31) != 0u : (n.x == nl.x) && (n.y == nl.y) && (n.z == nl.z);  // :438
+        const float nc = 1.0f, nt = 1.5f;
+        float nnt = into ? dm::fdiv<Fast>(nc, nt) : dm::fdiv<Fast>(nt, nc);   // :439
+        float ddn = Fast ? -__builtin_fabsf(dot_n_rd) : dot(rd, nl);
+        float cos2t = 1.0f - (nnt * nnt) * (1.0f - ddn * ddn);        // :440
+        if (cos2t >= 0.0f) {
+            MC_REGION(7);   // glass: refraction branch
+            const float sq2t = dm::fsqrt<Fast>(cos2t);
+            float k = (into ? 1.0f : -1.0f) * (ddn * nnt + sq2t);
+            v3 tdir = normalize_unit_combination<Fast, Slab>(rd * nnt - n * k);   // :441 (unit by Snell's law when rd, n are)
+            float aa = nt - nc, bb = nt + nc;
+            float R0 = dm::fdiv<Fast>(aa * aa, bb * bb);              // :442
+            // fast: dot(tdir, n) of the leaving ray is sqrt(cos2t) in exact arithmetic (tdir = rd*nnt - n*k, n = -nl)
+            float c = 1.0f - (into ? -ddn : (Fast && Slab ? sq2t : dot(tdir, n)));
+            float Re;                                                 // :443 R0 + (1 - R0) c^5
+            if constexpr (Fast) { const float c2 = c * c; Re = R0 + (1.0f - R0) * ((c2 * c2) * c); }   // c^5 through c^2, c^4
+            else Re = R0 + (((((1.0f - R0) * c) * c) * c) * c) * c;
+            float Tr = 1.0f - Re;
+            float P = 0.25f + 0.5f * Re;
+            bool pick_refl = rx < P;
+            // :442's RP = Re / P and TP = Tr / (1 - P): only the one :445 uses is formed (the same quotient)
+            const float weight = dm::fdiv<Fast>(pick_refl ? Re : Tr, pick_refl ? P : 1.0f - P);
+            rd = select(pick_refl, refl, tdir);                       // :444
+            accmat = accmat * weight;                                 // :445
+        } else {
+            rd = refl;                                                // :446
+        }
+    } else {
+        rd = refl;                                                    // :433
+    }
+    return rd;
+}
+
 // One sample: returns accrad (pathTracer.comp:356-449).  Box (fast math, slab scenes with SceneArgs::box_ok): see above.
 template <bool Fast, int NP, int NS, bool Slab, int Prec, bool Box = false>
 __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restrict__ lds_obj,
@@ -770,40 +812,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             if constexpr (Fast && Slab) {
                 rd = specular_bounce_fast(mat, rd, n, dot_n_rd, rnd.x, accmat);   // (the fast slab form, see there)
             } else {
-            const v3 refl = reflect(rd, n);
-            if (mat == 3) {
-                MC_REGION(6);   // glass
-                // fast: nl is n exactly when dot(n, rd) carries a sign bit, and dot(rd, nl) is then -|dot(n, rd)|
-                bool into = Fast ? (dm::as_uint(dot_n_rd) >> 31) != 0u : (n.x == nl.x) && (n.y == nl.y) && (n.z == nl.z);  // :438
-                const float nc = 1.0f, nt = 1.5f;
-                float nnt = into ? dm::fdiv<Fast>(nc, nt) : dm::fdiv<Fast>(nt, nc);   // :439
-                float ddn = Fast ? -__builtin_fabsf(dot_n_rd) : dot(rd, nl);
-                float cos2t = 1.0f - (nnt * nnt) * (1.0f - ddn * ddn);        // :440
-                if (cos2t >= 0.0f) {
-                    MC_REGION(7);   // glass: refraction branch
-                    const float sq2t = dm::fsqrt<Fast>(cos2t);
-                    float k = (into ? 1.0f : -1.0f) * (ddn * nnt + sq2t);
-                    v3 tdir = normalize_unit_combination<Fast, Slab>(rd * nnt - n * k);   // :441 (unit by Snell's law when rd, n are)
-                    float aa = nt - nc, bb = nt + nc;
-                    float R0 = dm::fdiv<Fast>(aa * aa, bb * bb);              // :442
-                    // fast: dot(tdir, n) of the leaving ray is sqrt(cos2t) in exact arithmetic (tdir = rd*nnt - n*k, n = -nl)
-                    float c = 1.0f - (into ? -ddn : (Fast && Slab ? sq2t : dot(tdir, n)));
-                    float Re;                                                 // :443 R0 + (1 - R0) c^5
-                    if constexpr (Fast) { const float c2 = c * c; Re = R0 + (1.0f - R0) * ((c2 * c2) * c); }   // c^5 through c^2, c^4
-                    else Re = R0 + (((((1.0f - R0) * c) * c) * c) * c) * c;
-                    float Tr = 1.0f - Re;
-                    float P = 0.25f + 0.5f * Re;
-                    bool pick_refl = rnd.x < P;
-                    // :442's RP = Re / P and TP = Tr / (1 - P): only the one :445 uses is formed (the same quotient)
-                    const float weight = dm::fdiv<Fast>(pick_refl ? Re : Tr, pick_refl ? P : 1.0f - P);
-                    rd = select(pick_refl, refl, tdir);                       // :444
-                    accmat = accmat * weight;                                 // :445
-                } else {
-                    rd = refl;                                                // :446
-                }
-            } else {
-                rd = refl;                                                    // :433
-            }
+            rd = specular_bounce_general<Fast, Slab>(mat, rd, n, nl, dot_n_rd, rnd.x, accmat);
             }   // (general form)
             if (!Slab || (!Box && !sc.materials_known)) ro = x;   // (slab scenes of known materials: moved ahead of the dispatch)
             emissive = 1.0f;                                              // :447

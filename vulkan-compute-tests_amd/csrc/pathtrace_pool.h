@@ -17,7 +17,13 @@
 // gfx950 executes an LDS float atomic at ~2 cycles per LANE — 131 LDS cycles per wave instruction, conflict or not — and the
 // kernel became LDS-bound: 33.6 ms.  profiles/r03_pool_v1_lds_atomics_pmc.txt.)
 //
-// Parity: each sample's arithmetic is exactly that of the fast closed-box round-synchronous kernel (the same inlined functions);
+// STRICT variant (Fast = false; bit-identical to the oracle like every strict kernel): the per-pixel sum must be the reference's —
+// samples added in sample order (:451-:452).  A lane therefore keeps a per-PATH accrad, writes accrad / spp into its sample's slot
+// of a result ring in LDS (four batches per pixel) when the path ends, and the pixel's 16 lanes add a batch's 16 results in sample
+// order — the fold of the round-synchronous kernels, fed from LDS — once every sample of the batch has ended (oldest live sample
+// of the pixel by a 4-step butterfly, only when a new batch is wanted).  Same decisions, same operations, same order: exact.
+//
+// Parity (fast): each sample's arithmetic is exactly that of the fast closed-box round-synchronous kernel (the same inlined functions);
 // what differs is the ORDER in which a pixel's fp32 contributions are added — the reference adds accrad/spp sample by sample
 // (:451-:452), here every lane sums the contributions of the samples it happened to trace and the S partial sums are added at
 // the end — a reassociation, relative 1e-6 of the pixel value, far inside the fast-math tolerance and the reason
@@ -39,11 +45,14 @@ namespace pt {
 constexpr uint32_t kPoolEntryFloats = 8;     // {rd.x, rd.y, rd.z, t | id (-1: nothing to trace), key0 = samp * maxDepth, rnd.x, rnd.y of key0}
 constexpr uint32_t kPoolRecordStride = 16;   // floats per staged record: {geo.xyz, p | colour.rgb, material + 256 * emits | emission.xyz, -}
 constexpr uint32_t kPoolRecordFloats = 9u * kPoolRecordStride;
-constexpr uint32_t kPoolWaveLdsFloats = 128u * kPoolEntryFloats;   // 64/S pixels x 2 batches x S entries
-constexpr size_t kPoolBlockLdsBytes = (kPoolRecordFloats + 4u * kPoolWaveLdsFloats) * sizeof(float);
+constexpr uint32_t kPoolStashFloats = 128u * kPoolEntryFloats;     // per wave: 64/S pixels x 2 batches x S entries
+constexpr uint32_t kPoolResultBatches = 4;                         // strict: result ring of 4 batches per pixel, 3 planes (x, y, z)
+constexpr uint32_t kPoolResultFloats = 64u * kPoolResultBatches * 3u;   // per wave: 64/S pixels x 4 batches x S samples x 3
+template <bool Fast> constexpr uint32_t pool_wave_lds_floats() { return kPoolStashFloats + (Fast ? 0u : kPoolResultFloats); }
+template <bool Fast> constexpr size_t pool_block_lds_bytes() { return (kPoolRecordFloats + 4u * pool_wave_lds_floats<Fast>()) * sizeof(float); }
 
-template <int S>
-__global__ void __launch_bounds__(256, MC_PT_POOL_WAVES) pathtrace_pool_kernel(PTArgs a) {
+template <bool Fast, int S>
+__global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_pool_kernel(PTArgs a) {
     extern __shared__ float lds_dyn[];
     float* lds_obj = lds_dyn;
     // The 9 records, re-packed for two 16-byte reads per bounce at address id << 6: the plane normal / sphere centre with the
@@ -59,7 +68,7 @@ __global__ void __launch_bounds__(256, MC_PT_POOL_WAVES) pathtrace_pool_kernel(P
         r[8] = o[4]; r[9] = o[5]; r[10] = o[6]; r[11] = 0.0f;
     }
     __syncthreads();
-    constexpr uint32_t TW = WaveTile<S>::w, TH = WaveTile<S>::h, Ring = 2u * (uint32_t)S;
+    constexpr uint32_t TW = WaveTile<S>::w, TH = WaveTile<S>::h, Ring = 2u * (uint32_t)S, RRing = kPoolResultBatches * (uint32_t)S;
     HotSlab hot;
     hot.load<MC_PT_POOL_HOT_VGPR>(a.scene);   // (uniform operands: this kernel has no vector registers to spare for copies)
     // A lane's pixel (pix = lane / S of the wave tile) and slot of a batch (sub = lane % S) never change.  What derives from them
@@ -82,8 +91,11 @@ __global__ void __launch_bounds__(256, MC_PT_POOL_WAVES) pathtrace_pool_kernel(P
     };
     // my pixel's coordinates (:349) stay: the RNG key of every bounce needs them; so does the base of its stash
     uint32_t gx, gy;
-    float* const gstash = lds_dyn + kPoolRecordFloats + (threadIdx.x >> 6) * kPoolWaveLdsFloats +
+    float* const gstash = lds_dyn + kPoolRecordFloats + (threadIdx.x >> 6) * pool_wave_lds_floats<Fast>() +
                           ((threadIdx.x & 63u) / (uint32_t)S) * (Ring * kPoolEntryFloats);
+    // strict: my pixel's result ring [3][RRing] (x, y, z planes) behind the wave's stash
+    float* const gres = lds_dyn + kPoolRecordFloats + (threadIdx.x >> 6) * pool_wave_lds_floats<Fast>() + kPoolStashFloats +
+                        ((threadIdx.x & 63u) / (uint32_t)S) * (3u * RRing);
     {
         const uint32_t tid = threadIdx.x, wave = tid >> 6, pix = (tid & 63u) / (uint32_t)S;
         gx = blockIdx.x * (2u * TW) + (wave & 1u) * TW + pix % TW;
@@ -95,7 +107,11 @@ __global__ void __launch_bounds__(256, MC_PT_POOL_WAVES) pathtrace_pool_kernel(P
     uint32_t batch = 0u;      // wave-uniform: batches produced; every pixel's stash has received batch * S entries
     uint32_t ghead = 0u;      // entries my pixel's lanes have taken (the same value in all S lanes)
     // ---- the state of a lane's path, and the radiance its paths have gathered
-    v3 ro{0, 0, 0}, rd{0, 0, 1}, accmat{1, 1, 1}, acc{0, 0, 0};
+    v3 ro{0, 0, 0}, rd{0, 0, 1}, accmat{1, 1, 1}, acc{0, 0, 0};   // acc: fast = this lane's partial sum; strict = the pixel's ordered sum
+    v3 accrad{0, 0, 0};       // strict: the radiance of the current path (:391, :422)
+    uint32_t cur = 0u;        // strict: index (within my pixel) of the sample this lane traces; its result slot is cur % RRing
+    uint32_t committed = 0u;  // strict: samples of my pixel already added to acc (the same value in all S lanes)
+    const float fspp = (float)a.spp;
     float emissive = 1.0f, t = 0.0f, occ[3] = {0.0f, 0.0f, 0.0f};
     int id = 0;
     uint32_t key = 0u, kend = 0u, krr = 0u;   // key0 + depth; key0 + maxDepth; key0 + 5 (:395: roulette while key > krr)
@@ -115,19 +131,43 @@ __global__ void __launch_bounds__(256, MC_PT_POOL_WAVES) pathtrace_pool_kernel(P
             const uint32_t gbits = (uint32_t)(deadm >> (me.lane - me.sub)) & (S == 32 ? ~0u : ((1u << (S & 31)) - 1u));
             const uint32_t need = (uint32_t)__builtin_popcount(gbits);
             uint32_t avail = batch * (uint32_t)S - ghead;
+            bool want = batch < n_batches && __ballot(need > avail) != 0ull && __ballot(avail > (uint32_t)S) == 0ull;
+            if constexpr (!Fast) {
+                if (want) {   // (uniform) add the batches whose samples have all ended, in order; then: is the result ring free?
+                    uint32_t oldest = alive ? cur : 0xffffffffu;                      // oldest sample a lane of my pixel still traces
+#pragma unroll
+                    for (uint32_t o = 1; o < (uint32_t)S; o <<= 1) {
+                        const uint32_t other = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((me.lane ^ o) << 2), (int)oldest);
+                        oldest = other < oldest ? other : oldest;
+                    }
+                    const uint32_t fin = oldest < ghead ? oldest : ghead;             // samples [0, fin) are taken and ended
+                    while (committed + (uint32_t)S <= fin) {
+                        for (uint32_t k = 0; k < (uint32_t)S; k++) {                  // :452 acc += accrad / spp, in sample order
+                            const uint32_t slot = (committed + k) & (RRing - 1u);
+                            acc.x += gres[slot]; acc.y += gres[RRing + slot]; acc.z += gres[2u * RRing + slot];
+                        }
+                        committed += (uint32_t)S;
+                    }
+                    want = __ballot((batch + 1u) * (uint32_t)S - committed > RRing) == 0ull;   // every pixel's ring has room
+                }
+            }
             // one more batch when a pixel wants more rays than it has — and every pixel's ring has room for S more
-            if (batch < n_batches && __ballot(need > avail) != 0ull && __ballot(avail > (uint32_t)S) == 0ull) {
+            if (want) {
                 const Lane g = my_lane(true);
                 const uint32_t samp = a.sample_begin + batch * (uint32_t)S + g.sub;
-                const v3 crd = camera_ray<true>(a, gx, gy, samp);
+                const v3 crd = camera_ray<Fast>(a, gx, gy, samp);
                 v3 oc0[3];
                 float occ0[3], ct;
 #pragma unroll
                 for (int i = 0; i < 3; i++) { oc0[i] = v3{a.cam_oc[i][0], a.cam_oc[i][1], a.cam_oc[i][2]}; occ0[i] = a.cam_occ[i]; }
-                int cid = intersect_slab<true>(hot, a.lc, crd, ct, false, occ0, oc0);
+                int cid = intersect_slab<Fast>(hot, a.lc, crd, ct, false, occ0, oc0);
                 // nothing to trace: a pixel outside the tile, a sample beyond the range; a camera ray that misses everything (:369)
                 // gathers nothing either
                 if (!(g.valid && samp < a.sample_end)) cid = -1;
+                if constexpr (!Fast) {   // such a sample's result is a zero (adding +0 changes no bit of the sum)
+                    const uint32_t slot = (batch * (uint32_t)S + g.sub) & (RRing - 1u);
+                    if (cid < 0) { gres[slot] = 0.0f; gres[RRing + slot] = 0.0f; gres[2u * RRing + slot] = 0.0f; }
+                }
                 float4* e = reinterpret_cast<float4*>(gstash + ((batch * (uint32_t)S + g.sub) & (Ring - 1u)) * kPoolEntryFloats);
                 e[0] = make_float4(crd.x, crd.y, crd.z, ct);
                 const v3 r0 = rand01(gx, gy, samp * a.max_depth);           // :393 at depth 0 (no roulette there: z unused)
@@ -140,6 +180,7 @@ __global__ void __launch_bounds__(256, MC_PT_POOL_WAVES) pathtrace_pool_kernel(P
                 const float4* q = reinterpret_cast<const float4*>(gstash + ((ghead + rank) & (Ring - 1u)) * kPoolEntryFloats);
                 const float4 q0 = q[0], q1 = q[1];
                 rd = v3{q0.x, q0.y, q0.z}; t = q0.w;
+                if constexpr (!Fast) { cur = ghead + rank; accrad = v3{0.0f, 0.0f, 0.0f}; }   // :361
                 id = (int)dm::as_uint(q1.x);
                 key = dm::as_uint(q1.y); kend = key + a.max_depth; krr = key + 5u;
                 rx = q1.z; ry = q1.w;
@@ -167,43 +208,57 @@ __global__ void __launch_bounds__(256, MC_PT_POOL_WAVES) pathtrace_pool_kernel(P
                 const uint32_t mbits = dm::as_uint(o1.w);
                 const int mat = (int)(mbits & 255u);                              // :378/:384
                 const float p = o0.w;                                             // :394
-                v3 n = is_sphere ? normalize<true>(x - geo) : geo;                // :381/:387
+                v3 n = is_sphere ? normalize<Fast>(x - geo) : geo;                // :381/:387
                 const float dot_n_rd = dot(n, rd);
-                const uint32_t flip = ~dm::as_uint(dot_n_rd) & 0x80000000u;       // :390 nl = dot(n, rd) < 0 ? n : -n
-                v3 nl{dm::as_float(dm::as_uint(n.x) ^ flip), dm::as_float(dm::as_uint(n.y) ^ flip), dm::as_float(dm::as_uint(n.z) ^ flip)};
+                v3 nl;                                                            // :390 nl = dot(n, rd) < 0 ? n : -n
+                if constexpr (Fast) {   // (the sign bit of the dot product, inverted, flips n — trace_sample)
+                    const uint32_t flip = ~dm::as_uint(dot_n_rd) & 0x80000000u;
+                    nl = v3{dm::as_float(dm::as_uint(n.x) ^ flip), dm::as_float(dm::as_uint(n.y) ^ flip), dm::as_float(dm::as_uint(n.z) ^ flip)};
+                } else {
+                    nl = dot_n_rd < 0.0f ? n : -n;
+                }
+                v3& rad = Fast ? acc : accrad;                                    // where gathered radiance goes (see the header)
                 if (__ballot(mbits >= 256u) != 0ull) {                            // :391 (non-emitters add a zero: box_ok)
                     const float4 o2 = obj[2];
-                    acc = acc + (accmat * v3{o2.x, o2.y, o2.z}) * emissive;
+                    rad = rad + (accmat * v3{o2.x, o2.y, o2.z}) * emissive;
                 }
                 accmat = accmat * col;                                            // :392
                 const v3 rnd{rx, ry, 0.0f};                                       // :393 (drawn at the end of the previous bounce)
-                if (key > krr) accmat = divs<true>(accmat, p);                    // :395, :397 (:396 was decided there too)
+                if (key > krr) accmat = divs<Fast>(accmat, p);                    // :395, :397 (:396 was decided there too)
                 bool go = true;
                 {
                 ro = x;                                                           // :429, :434, :447
                 if (mat == 1) {                                                   // :400 diffuse
+                    v3 accmat_over_pi{0.0f, 0.0f, 0.0f};                          // strict: :422's accmat / pi, once per bounce
+                    if constexpr (!Fast) accmat_over_pi = divs_recip<Fast>(accmat, kPi, kInvPi);
 #pragma unroll
                     for (int i = 0; i < 3; i++) {                                 // :403
                         if (!((a.scene.emissive_mask >> i) & 1u)) continue;       // :407 (uniform)
                         const float* ls = a.scene.obj + 12 * (6 + i);
                         v3 le{ls[4], ls[5], ls[6]};
                         float cos_a_max;
-                        v3 l = light_sample_direction<true>(xoc[i], occ[i], hot.r2[i], rnd, cos_a_max);   // :408-:413
-                        if (shadow_reaches_sphere<true>(hot, x, l, i, xoc[i], occ)) {                      // :420
-                            const float scale = __builtin_fmaxf(dot(l, nl), 0.0f) * (2.0f - (cos_a_max + cos_a_max));   // :421-:422
-                            acc = acc + (accmat * le) * scale;
+                        v3 l = light_sample_direction<Fast>(xoc[i], occ[i], hot.r2[i], rnd, cos_a_max);   // :408-:413
+                        if (shadow_reaches_sphere<Fast>(hot, x, l, i, xoc[i], occ)) {                      // :420
+                            if constexpr (Fast) {
+                                const float scale = __builtin_fmaxf(dot(l, nl), 0.0f) * (2.0f - (cos_a_max + cos_a_max));   // :421-:422
+                                rad = rad + (accmat * le) * scale;
+                            } else {
+                                const float omega = (2.0f * kPi) * (1.0f - cos_a_max);                     // :421
+                                rad = rad + ((accmat_over_pi * dm::gmax(dot(l, nl), 0.0f)) * le) * omega;  // :422
+                            }
                         }
                     }
-                    rd = cosine_bounce<true, true>(nl, rnd);                      // :426-:428
+                    rd = cosine_bounce<Fast, true>(nl, rnd);                      // :426-:428
                     emissive = 0.0f;                                              // :429
                 } else {                                                          // :432 mirror, :437 glass (box_ok: 2 or 3)
-                    rd = specular_bounce_fast(mat, rd, n, dot_n_rd, rnd.x, accmat);
+                    if constexpr (Fast) rd = specular_bounce_fast(mat, rd, n, dot_n_rd, rnd.x, accmat);
+                    else rd = specular_bounce_general<false, true>(mat, rd, n, nl, dot_n_rd, rnd.x, accmat);
                     emissive = 1.0f;                                              // :447
                 }
                 key++;
                 go = key != kend;                                                 // :367 depth limit
                 if (go) {
-                    id = intersect_slab<true>(hot, ro, rd, t, false, occ, xoc);
+                    id = intersect_slab<Fast>(hot, ro, rd, t, false, occ, xoc);
                     go = id >= 0;                                                 // :369
                 }
                 if (go) {                                                         // the next bounce's random numbers and roulette
@@ -215,44 +270,61 @@ __global__ void __launch_bounds__(256, MC_PT_POOL_WAVES) pathtrace_pool_kernel(P
                         // a path the roulette ends has still gathered the emission of this hit (:391 precedes :396)
                         if (__ballot(!go && dm::as_uint(nobj[1].w) >= 256u) != 0ull) {
                             const float4 o2 = nobj[2];
-                            if (!go) acc = acc + (accmat * v3{o2.x, o2.y, o2.z}) * emissive;
+                            if (!go) rad = rad + (accmat * v3{o2.x, o2.y, o2.z}) * emissive;
                         }
                     }
                 }
+                }
+                if constexpr (!Fast) {
+                    if (!go) {   // the path has ended: :452's accrad / samps.y into the sample's slot of the result ring
+                        const v3 q = divs_recip<Fast>(accrad, fspp, a.inv_spp);
+                        const uint32_t slot = cur & (RRing - 1u);
+                        gres[slot] = q.x; gres[RRing + slot] = q.y; gres[2u * RRing + slot] = q.z;
+                    }
                 }
                 alive = go;
             }
         }
     }
-    // ---- :452-:453: the S partial sums of a pixel, added in lane order by each of its lanes (all S copies identical)
     float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    auto from_lane = [](float v, uint32_t src) {
-        return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src << 2), __float_as_int(v)));
-    };
     const Lane fin = my_lane(true);
-    for (uint32_t k = 0; k < (uint32_t)S; k++) {
-        const uint32_t src = fin.lane - fin.sub + k;
-        sum.x += from_lane(acc.x, src); sum.y += from_lane(acc.y, src); sum.z += from_lane(acc.z, src);
+    if constexpr (Fast) {
+        // ---- :452-:453: the S partial sums of a pixel, added in lane order by each of its lanes (all S copies identical)
+        auto from_lane = [](float v, uint32_t src) {
+            return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src << 2), __float_as_int(v)));
+        };
+        for (uint32_t k = 0; k < (uint32_t)S; k++) {
+            const uint32_t src = fin.lane - fin.sub + k;
+            sum.x += from_lane(acc.x, src); sum.y += from_lane(acc.y, src); sum.z += from_lane(acc.z, src);
+        }
+        sum.x *= a.inv_spp; sum.y *= a.inv_spp; sum.z *= a.inv_spp;
+    } else {
+        // ---- every sample of the pool has ended: the batches not yet added, in sample order (entries beyond the sample range hold zeros)
+        while (committed < n_batches * (uint32_t)S) {
+            for (uint32_t k = 0; k < (uint32_t)S; k++) {
+                const uint32_t slot = (committed + k) & (RRing - 1u);
+                acc.x += gres[slot]; acc.y += gres[RRing + slot]; acc.z += gres[2u * RRing + slot];
+            }
+            committed += (uint32_t)S;
+        }
+        sum = make_float4(acc.x, acc.y, acc.z, 0.0f);
     }
-    sum.x *= a.inv_spp; sum.y *= a.inv_spp; sum.z *= a.inv_spp;
-    if (a.sample_end == a.spp) {
-        sum.x = dm::fpow<true>(dm::gmin(dm::gmax(sum.x, 0.0f), 1.0f), 0.45f) * 255.0f + 0.5f;
-        sum.y = dm::fpow<true>(dm::gmin(dm::gmax(sum.y, 0.0f), 1.0f), 0.45f) * 255.0f + 0.5f;
-        sum.z = dm::fpow<true>(dm::gmin(dm::gmax(sum.z, 0.0f), 1.0f), 0.45f) * 255.0f + 0.5f;
+    if (a.sample_end == a.spp) {                                                // :453 after sample spp-1
+        sum.x = dm::fpow<Fast>(dm::gmin(dm::gmax(sum.x, 0.0f), 1.0f), 0.45f) * 255.0f + 0.5f;
+        sum.y = dm::fpow<Fast>(dm::gmin(dm::gmax(sum.y, 0.0f), 1.0f), 0.45f) * 255.0f + 0.5f;
+        sum.z = dm::fpow<Fast>(dm::gmin(dm::gmax(sum.z, 0.0f), 1.0f), 0.45f) * 255.0f + 0.5f;
     }
     if (fin.valid && fin.sub == 0u) a.out[(size_t)fin.ty * a.W + gx] = sum;
 }
 
-template <int S> inline int launch_pool_one(const PTArgs& a, uint32_t tile_rows, hipStream_t s) {
+template <bool Fast, int S> inline int launch_pool_one(const PTArgs& a, uint32_t tile_rows, hipStream_t s) {
     dim3 grid((a.W + block_w<S>() - 1u) / block_w<S>(), (tile_rows + block_h<S>() - 1u) / block_h<S>());
-    hipLaunchKernelGGL(pathtrace_pool_kernel<S>, grid, dim3(256), kPoolBlockLdsBytes, s, a);
+    hipLaunchKernelGGL((pathtrace_pool_kernel<Fast, S>), grid, dim3(256), pool_block_lds_bytes<Fast>(), s, a);
     return MC_OK;
 }
-// variant 4 of launch_fast: S as chosen by the host (1, 4 or 16 lanes per pixel in a batch)
-inline int launch_pool(const PTArgs& a, int S, uint32_t tile_rows, hipStream_t s) {
-    if (S == 1) return launch_pool_one<1>(a, tile_rows, s);
-    if (S == 4) return launch_pool_one<4>(a, tile_rows, s);
-    if (S == 16) return launch_pool_one<16>(a, tile_rows, s);
+// variant 4 of launch_fast / launch_strict: 16 lanes per pixel and batch (the host never passes anything else)
+template <bool Fast> inline int launch_pool(const PTArgs& a, int S, uint32_t tile_rows, hipStream_t s) {
+    if (S == 16) return launch_pool_one<Fast, 16>(a, tile_rows, s);
     return MC_ERR_INVALID_ARGUMENT;
 }
 
