@@ -96,3 +96,31 @@ def test_apps_gpu_postprocess_and_precision_options(B, O, tmp_path):
     _, lut_u8 = O.mandel_lut(600)
     it = O.mandelbrot_iters(64, 48, 600, view=O.make_view(-0.7436438870371587, 0.13182590420531198, 1e-8, 6.666666666666667e-9), precision=1)
     assert np.array_equal(np.asarray(Image.open(tmp_path / "mandelbrot.png").convert("RGBA")), lut_u8[it])
+
+
+def test_apps_write_the_reference_codecs_bytes(B, O, tmp_path):
+    """north_star: "bit-identical PNG".  The standalone apps' files are, byte for byte, what the reference's codec writes for the
+    same pixels (host/pngReference.cpp) — checked against that codec where it is available (oracle/_ref), and against the SHA-256
+    pinned from it for the 256 x 256, M = 128 Mandelbrot; `--fast-png` selects the parallel writer (same pixels, other bytes)."""
+    import hashlib
+    from PIL import Image
+    from conftest import GOLDEN
+    bindir = os.path.join(os.path.dirname(os.path.dirname(B.LIB_PATH)), "bin")
+    r = subprocess.run([os.path.join(bindir, "mandelbrot"), "--width", "256", "--height", "256", "--quiet"], capture_output=True,
+                       text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    png = open(tmp_path / "mandelbrot.png", "rb").read()
+    golden = open(os.path.join(GOLDEN, "mandelbrot_256_M128_lodepng.sha256")).read().split()[0]
+    assert hashlib.sha256(png).hexdigest() == golden
+    r = subprocess.run([os.path.join(bindir, "pathtracer"), "8", "40", "--quiet"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    png = open(tmp_path / "pathtracer.png", "rb").read()
+    ref = O.pathtrace(60, 40, 8, math_mode=O.MATH_MC)
+    exp = O.rotate180(O.float_to_rgba8(ref, 1.0).reshape(40, 60, 4), 60, 40)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "pathtracer.png").convert("RGBA")), exp)
+    if O.ref_lodepng() is not None:
+        assert png == O.ref_png_encode(np.ascontiguousarray(exp), 60, 40)
+    r = subprocess.run([os.path.join(bindir, "pathtracer"), "8", "40", "--quiet", "--fast-png", "--out", "fast.png"], capture_output=True,
+                       text=True, cwd=tmp_path)
+    assert r.returncode == 0
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "fast.png").convert("RGBA")), exp)

@@ -92,8 +92,11 @@ def fuzz_pathtrace(rng, ctx, B, O):
     if rng.random() < 0.05:   # extreme radii: roots far outside / tiny discriminants
         spheres[rng.integers(3), 3] = np.float32(rng.choice([1e-3, 1e-2, 5.0, 30.0]))
     W, H, spp = int(rng.integers(1, 40)), int(rng.integers(1, 28)), int(rng.integers(1, 20))
+    if rng.random() < 0.25:   # sample counts beyond the pool kernel's batch (16) and result-ring (64) sizes, on a small image
+        W, H, spp = int(rng.integers(1, 12)), int(rng.integers(1, 10)), int(rng.integers(20, 200))
     depth = int(rng.choice([12, 12, 12, 3, 7, 15]))
-    flags = int(rng.choice([0, B.pt_force_s(1), B.pt_force_s(4), B.pt_force_s(16), B.PT_GENERIC_KERNEL]))
+    # 0: the automatic choice (the strict sample-pool kernel for closed-box scenes, else the round-synchronous kernels)
+    flags = int(rng.choice([0, 0, 0, B.pt_force_s(1), B.pt_force_s(4), B.pt_force_s(16), B.PT_GENERIC_KERNEL, B.PT_NO_POOL_KERNEL]))
     cls = B.pathtrace_scene_class(planes, spheres)
     out = ctx.pathtrace(B.pathtrace_params(W, H, spp, max_depth=depth, flags=flags), planes=planes, spheres=spheres)
     ref = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC, max_depth=depth)

@@ -1,5 +1,8 @@
 #include "computeApp.h"
 
+#include "pngReference.h"
+#include "pngWriter.h"
+
 #include <chrono>
 
 ComputeApp::~ComputeApp() {
@@ -43,4 +46,12 @@ void ComputeApp::run() {
     auto t1 = std::chrono::steady_clock::now();
     lastRunMs = std::chrono::duration<double, std::milli>(t1 - t0).count();
     if (!quiet) { printf("run() finished in %.3f ms\n", lastRunMs); fflush(stdout); }
+}
+
+std::string ComputeApp::writePng(const char* filename, const uint8_t* rgba8, uint32_t w, uint32_t h) const {
+    if (!fastPng) {
+        const std::string err = pngref::encodeFile(filename, rgba8, w, h);
+        if (err != "alpha") return err;   // ("alpha": not an opaque image — outside the reference-compatible encoder's contract)
+    }
+    return pngwriter::encodeFile(filename, rgba8, w, h, pngThreads);
 }

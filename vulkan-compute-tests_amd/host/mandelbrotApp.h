@@ -68,7 +68,7 @@ struct MandelbrotApp : public ComputeApp {
         if (gpuPostprocess) image.swap(rgba8);  // already converted on the device with the same cast semantics
         else getRenderedImage(image, resx, resy, scaleFactor);
         printf("writing %s\n", png_filename);
-        std::string err = pngwriter::encodeFile(png_filename, image.data(), resx, resy, pngThreads);
+        std::string err = writePng(png_filename, image.data(), resx, resy);
         if (!err.empty()) printf("encoder error: %s", err.c_str());   // printed, not thrown (mandelbrotApp.h:183)
     }
 

@@ -126,7 +126,7 @@ struct PathtracerApp : public ComputeApp {
                 }
             }
         }
-        std::string err = pngwriter::encodeFile(png_filename, image.data(), resx, resy, pngThreads);
+        std::string err = writePng(png_filename, image.data(), resx, resy);
         if (!err.empty()) printf("encoder error: %s", err.c_str());
     }
 
