@@ -59,6 +59,27 @@ def _worker(rank, world, port, W, H, q):
             g = S.gather_tiles(torch.from_numpy(pad), rank, world)
             if rank == 0:
                 results[name] = _deinterleave_numpy(g.numpy(), H, world, S.ROW_BLOCK)
+            # the step loop bench.py runs (S.Exchange: receive buffers allocated once, two buffer sets used alternately): three
+            # steps with different tile contents; what rank 0 re-assembles in step i must be step i's image
+            ex = S.Exchange(rank, world, pad.shape, torch.from_numpy(pad).dtype, "cpu")
+            seen = []
+            for i in range(3):
+                t = ex.tile(i)
+                t.copy_(torch.from_numpy(pad))
+                if name == "mandelbrot":
+                    t += i                           # a different image per step (same on every rank)
+                else:
+                    t *= float(i + 1)
+                ex.submit(i, lambda recv, stream: seen.append(_deinterleave_numpy(recv.numpy().copy(), H, world, S.ROW_BLOCK)))
+            ex.finish()
+            if rank == 0:
+                assert len(seen) == 3 and ex.bytes_per_rank == pad.nbytes
+                for i, img in enumerate(seen):
+                    exp = results[name] + i if name == "mandelbrot" else results[name] * np.float32(i + 1)
+                    if name == "mandelbrot":         # padding rows of partial tiles also received + i: compare owned rows only
+                        assert np.array_equal(img, exp), (name, i)
+                    else:
+                        assert np.array_equal(img.view(np.uint32), exp.view(np.uint32)), (name, i)
         dist.barrier()
         if rank == 0:
             q.put(results)

@@ -97,19 +97,22 @@ class Exchange:
             self.pending[k] = None
         return self.tiles[k]
 
+    def _stream_handle(self):
+        return torch.cuda.current_stream().cuda_stream if self.tiles[0].is_cuda else 0
+
     def submit(self, i, assemble=None, done_event=None):
         if self.n == 1:
             return
         k = i % 2
         tile = self.tiles[k]
-        if self.gloo:
+        if self.gloo:   # (tiles on the GPU: staged through the host; tiles on the CPU — the CPU tests — gathered as they are)
             host = tile.cpu()
             bufs = list(torch.empty((self.n,) + tuple(host.shape), dtype=host.dtype).unbind(0)) if self.rank == self.dst else None
             dist.gather(host, bufs, dst=self.dst)
             if self.rank == self.dst:
                 self.recv[k].copy_(torch.stack(bufs))
                 if assemble is not None:
-                    assemble(self.recv[k], torch.cuda.current_stream().cuda_stream)
+                    assemble(self.recv[k], self._stream_handle())
             if done_event is not None:
                 done_event.record()
             return
