@@ -325,6 +325,15 @@ int mc_mandelbrot_assemble_device_async(mc_context* ctx, const mc_mandelbrot_par
                                       pick_stream(ctx, stream));
 }
 
+// Experiment only (tools/mandel_order_probe.py; not declared in the header): dispatch the Mandelbrot tiles in the order given
+// (device array of n tile indices, tile = tile_y * tiles_x + tile_x), or in natural order again with d_order = NULL.
+int mc_debug_mandelbrot_tile_order(mc_context* ctx, const void* d_order, size_t n) {
+    if (!ctx) return MC_ERR_INVALID_ARGUMENT;
+    ctx->debug_tile_order = d_order;
+    ctx->debug_tile_order_n = d_order ? n : 0;
+    return MC_OK;
+}
+
 // ---- Mandelbrot -------------------------------------------------------------------------------------
 int mc_mandelbrot_default_params(uint32_t width, uint32_t height, mc_mandelbrot_params* p) {
     if (!p) return MC_ERR_INVALID_ARGUMENT;
