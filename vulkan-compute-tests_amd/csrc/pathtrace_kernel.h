@@ -354,7 +354,10 @@ struct HotSlab {
 // (w_neg + o[a]) / |d[a]|, equals ((-w_neg) - o[a]) / d[a] bit for bit: negation is exact, (-x) - y = -(x + y) under
 // round-to-nearest, and (-n) / (-d) = n / d (IEEE divide; v_rcp_f32 is odd, tested).  So both cases are
 // (W - o[a]) / d[a] with W = pos ? w_pos : -w_neg: one select and one subtraction instead of two additions and a select.
-template <bool Fast>
+// Closed (fast math, SceneArgs::box_ok, origin inside the box): the nearest facing plane IS a hit — the |d_a| > 1e-7 / t < 1e20
+// tests of :119 / :336 can only fail for a ray that runs along a wall it starts on to within 1e-7, or a NaN ray (which then
+// gathers nothing: every later comparison with its NaN t is false) — so they and the final "anything hit?" select are dropped.
+template <bool Fast, bool Closed = false>
 __device__ __forceinline__ int intersect_slab(const HotSlab& h, v3 o, v3 d, float& t_out, bool shadow_skip_planes,
                                               const float* occ = nullptr,     // occ[i] = dot(c_i - o, c_i - o) and
                                               const v3* oc_at_o = nullptr) {  // oc_at_o[i] = c_i - o if the caller has them
@@ -384,7 +387,8 @@ __device__ __forceinline__ int intersect_slab(const HotSlab& h, v3 o, v3 d, floa
             bn = nearer ? num[a] : bn; bd = nearer ? den[a] : bd; bid = nearer ? pid[a] : bid;
         }
         const float dd = dm::fdiv<Fast>(bn, bd);
-        if (__builtin_fabsf(bd) > h.tri_eps && dd < t) { t = dd; id = bid; }
+        if constexpr (Closed) { t = dd; id = bid; }
+        else if (__builtin_fabsf(bd) > h.tri_eps && dd < t) { t = dd; id = bid; }
     } else if (!shadow_skip_planes) {
 #pragma unroll
         for (int a = 0; a < 3; a++) {
@@ -411,6 +415,7 @@ __device__ __forceinline__ int intersect_slab(const HotSlab& h, v3 o, v3 d, floa
         }
     }
     t_out = t;
+    if constexpr (Closed) return id;
     return (t < h.inf) ? id : -1;                                            // :336
 }
 
@@ -601,6 +606,24 @@ template <bool Fast, bool Unit> __device__ __forceinline__ v3 cosine_bounce(v3 w
     return Fast ? normalize_unit_combination<Fast, Unit>((u * (c1 * r2s) + v * (s1 * r2s)) + w * dm::fsqrt<Fast>(1.0f - r2))
                 : normalize_unit_combination<Fast, Unit>(((u * c1) * r2s + (v * s1) * r2s) + w * dm::fsqrt<Fast>(1.0f - r2));   // :428
 }
+// The same bounce around the inward normal of an axis-aligned WALL of a closed box (fast math): w = sigma * e_a, so the basis
+// of :427 is two signed axis vectors and :428's combination is a signed permutation of (c1 r2s, s1 r2s, sqrt(1 - r2)) — worked out
+// from tangent_u / cross above for the three axes; every component is the one non-zero term of the general form (its other two terms
+// are products with exact zeros, its factor 1/|..| is v_rsq_f32(1) = 1), i.e. the same values, without the basis: no v_rsq_f32, no
+// cross product, no 3 x 3 combination.  `id` = the wall's slab id 2a + (normal is +e_a); a hit wall faces the ray (:119), so
+// nl = -n and sigma is negative exactly for the odd ids.
+__device__ __forceinline__ v3 cosine_bounce_wall(int id, v3 rnd) {
+    const float r2s = dm::fsqrt<true>(rnd.y);
+    float s1, c1;
+    dm::sincos_angle<true>(0.0f, rnd.x, s1, c1);
+    const float A = c1 * r2s, B = s1 * r2s, C = dm::fsqrt<true>(1.0f - rnd.y);
+    const uint32_t sb = (uint32_t)id << 31;
+    const float sC = dm::as_float(dm::as_uint(C) ^ sb), sA = dm::as_float(dm::as_uint(A) ^ sb);
+    const float nsA = dm::as_float(dm::as_uint(sA) ^ 0x80000000u);
+    const bool a0 = id < 2, a1 = id < 4;   // (a1 is read only where a0 is false)
+    return v3{a0 ? sC : B, a0 ? B : (a1 ? sC : nsA), a0 ? nsA : (a1 ? sA : sC)};
+}
+
 // Mirror / glass bounce in the fast slab form (:432-:447): every outcome is rd*alpha + n*beta — reflection (1, -2 dot(n, rd)),
 // refraction (nnt, -k) — so the scalars are selected and ONE direction is formed; cos of the leaving ray = sqrt(cos2t), c^5
 // through c^2.  mat is 2 or 3; dot_n_rd = dot(n, rd); rx = rnd.x; accmat receives :445's weight.

@@ -43,7 +43,7 @@ namespace mc {
 namespace pt {
 
 constexpr uint32_t kPoolEntryFloats = 8;     // {rd.x, rd.y, rd.z, t | id (-1: nothing to trace), key0 = samp * maxDepth, rnd.x, rnd.y of key0}
-constexpr uint32_t kPoolRecordStride = 16;   // floats per staged record: {geo.xyz, p | colour.rgb, material + 256 * emits | emission.xyz, -}
+constexpr uint32_t kPoolRecordStride = 16;   // floats per staged record: {geo.xyz, p (fast: 1 / p) | colour.rgb, material + 256 * emits | emission.xyz, p}
 constexpr uint32_t kPoolRecordFloats = 9u * kPoolRecordStride;
 constexpr uint32_t kPoolStashFloats = 128u * kPoolEntryFloats;     // per wave: 64/S pixels x 2 batches x S entries
 constexpr uint32_t kPoolResultBatches = 4;                         // strict: result ring of 4 batches per pixel, 3 planes (x, y, z)
@@ -58,14 +58,17 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
     // The 9 records, re-packed for two 16-byte reads per bounce at address id << 6: the plane normal / sphere centre with the
     // roulette probability max(max(c.x, c.y), c.z) (:394), the colour with the material code int(floor(m + 0.5)) (:378/:384)
     // and an "emits" flag as integer bits — the same fp32 operations on the same operands as evaluating them at every bounce.
+    // Fast math: slot 3 holds v_rcp_f32(p), the factor :397's division multiplies by — formed once per block instead of once
+    // per bounce and lane (a transcendental blocks the SIMD for 8 cycles); p itself, which :396 compares with, is in slot 11.
     if (threadIdx.x < 9u) {
         const float* o = a.scene.obj + 12u * threadIdx.x;
         float* r = lds_obj + kPoolRecordStride * threadIdx.x;
-        r[0] = o[0]; r[1] = o[1]; r[2] = o[2]; r[3] = dm::gmax(dm::gmax(o[8], o[9]), o[10]);
+        const float p = dm::gmax(dm::gmax(o[8], o[9]), o[10]);
+        r[0] = o[0]; r[1] = o[1]; r[2] = o[2]; r[3] = Fast ? dm::fdiv<Fast>(1.0f, p) : p;
         r[4] = o[8]; r[5] = o[9]; r[6] = o[10];
         const uint32_t emits = (o[4] != 0.0f || o[5] != 0.0f || o[6] != 0.0f) ? 256u : 0u;
         r[7] = dm::as_float((uint32_t)(int)__builtin_floorf(o[11] + 0.5f) | emits);
-        r[8] = o[4]; r[9] = o[5]; r[10] = o[6]; r[11] = 0.0f;
+        r[8] = o[4]; r[9] = o[5]; r[10] = o[6]; r[11] = p;
     }
     __syncthreads();
     constexpr uint32_t TW = WaveTile<S>::w, TH = WaveTile<S>::h, Ring = 2u * (uint32_t)S, RRing = kPoolResultBatches * (uint32_t)S;
@@ -160,7 +163,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                 float occ0[3], ct;
 #pragma unroll
                 for (int i = 0; i < 3; i++) { oc0[i] = v3{a.cam_oc[i][0], a.cam_oc[i][1], a.cam_oc[i][2]}; occ0[i] = a.cam_occ[i]; }
-                int cid = intersect_slab<Fast>(hot, a.lc, crd, ct, false, occ0, oc0);
+                int cid = intersect_slab<Fast, Fast>(hot, a.lc, crd, ct, false, occ0, oc0);
                 // nothing to trace: a pixel outside the tile, a sample beyond the range; a camera ray that misses everything (:369)
                 // gathers nothing either
                 if (!(g.valid && samp < a.sample_end)) cid = -1;
@@ -207,7 +210,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                 v3 col{o1.x, o1.y, o1.z};
                 const uint32_t mbits = dm::as_uint(o1.w);
                 const int mat = (int)(mbits & 255u);                              // :378/:384
-                const float p = o0.w;                                             // :394
+                const float p = o0.w;                                             // :394 (fast: its reciprocal)
                 v3 n = is_sphere ? normalize<Fast>(x - geo) : geo;                // :381/:387
                 const float dot_n_rd = dot(n, rd);
                 v3 nl;                                                            // :390 nl = dot(n, rd) < 0 ? n : -n
@@ -224,7 +227,8 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                 }
                 accmat = accmat * col;                                            // :392
                 const v3 rnd{rx, ry, 0.0f};                                       // :393 (drawn at the end of the previous bounce)
-                if (key > krr) accmat = divs<Fast>(accmat, p);                    // :395, :397 (:396 was decided there too)
+                if constexpr (Fast) accmat = accmat * (key > krr ? p : 1.0f);     // :395, :397 (:396 was decided there too)
+                else if (key > krr) accmat = divs<Fast>(accmat, p);
                 bool go = true;
                 {
                 ro = x;                                                           // :429, :434, :447
@@ -248,7 +252,13 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                             }
                         }
                     }
-                    rd = cosine_bounce<Fast, true>(nl, rnd);                      // :426-:428
+                    if constexpr (Fast) {                                         // :426-:428
+                        // (uniform: no lane of the wave bounces off a diffuse SPHERE — the light — in almost every iteration)
+                        if (__ballot(is_sphere) == 0ull) rd = cosine_bounce_wall(id, rnd);
+                        else rd = cosine_bounce<Fast, true>(nl, rnd);
+                    } else {
+                        rd = cosine_bounce<Fast, true>(nl, rnd);
+                    }
                     emissive = 0.0f;                                              // :429
                 } else {                                                          // :432 mirror, :437 glass (box_ok: 2 or 3)
                     if constexpr (Fast) rd = specular_bounce_fast(mat, rd, n, dot_n_rd, rnd.x, accmat);
@@ -258,7 +268,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                 key++;
                 go = key != kend;                                                 // :367 depth limit
                 if (go) {
-                    id = intersect_slab<Fast>(hot, ro, rd, t, false, occ, xoc);
+                    id = intersect_slab<Fast, Fast>(hot, ro, rd, t, false, occ, xoc);
                     go = id >= 0;                                                 // :369
                 }
                 if (go) {                                                         // the next bounce's random numbers and roulette
@@ -266,7 +276,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                     rx = rn.x; ry = rn.y;
                     if (key > krr) {                                              // :395 depth > 5
                         const float4* nobj = reinterpret_cast<const float4*>(lds_obj + kPoolRecordStride * (uint32_t)id);
-                        go = !(rn.z >= nobj[0].w);                                // :396
+                        go = !(rn.z >= nobj[2].w);                                // :396
                         // a path the roulette ends has still gathered the emission of this hit (:391 precedes :396)
                         if (__ballot(!go && dm::as_uint(nobj[1].w) >= 256u) != 0ull) {
                             const float4 o2 = nobj[2];
