@@ -174,6 +174,16 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
                 const float c = a.scene.obj[12 * i + k];
                 if (!(c >= 0.0f && c <= 1.0f)) a.scene.emit_skip_ok = 0u;     // also rejects NaN
             }
+        // the three spheres pairwise disjoint, with a margin far above fp32 rounding of the kernel's squared distances
+        a.scene.spheres_disjoint = 1u;
+        for (uint32_t i = 0; i < 3; i++)
+            for (uint32_t j = i + 1; j < 3; j++) {
+                const float* si = spheres + 12 * i;
+                const float* sj = spheres + 12 * j;
+                const double dx = (double)si[0] - sj[0], dy = (double)si[1] - sj[1], dz = (double)si[2] - sj[2];
+                const double gap = std::sqrt(dx * dx + dy * dy + dz * dz) - (std::fabs((double)si[3]) + std::fabs((double)sj[3]));
+                if (!(gap > 1e-3 * (1.0 + std::fabs((double)si[3]) + std::fabs((double)sj[3])))) a.scene.spheres_disjoint = 0u;   // also NaN
+            }
         // closed-box fast kernel: no ray may ever leave the box (pathtrace_kernel.h, intersect_box)
         a.scene.box_ok = (a.scene.nee_skip_planes && a.scene.materials_known && !glass_wall && a.scene.emit_skip_ok) ? 1u : 0u;
     } else {      // any other scene: device buffer [records | emissive sphere indices], staged into LDS by the kernel
@@ -222,7 +232,10 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
         const bool aligned = p->row_begin % th == 0u && (a.row_block == 0u || (a.row_block % th == 0u && a.row_stride % th == 0u)) &&
                              (p->row_end % th == 0u || p->row_end == p->height);
         const bool fits = p->max_depth >= 1u && (uint64_t)p->spp * p->max_depth < (1ull << 32) && p->width < (1u << 24);
-        if (((p->flags >> 8) & 0xffu) == 0u && !(p->flags & MC_PT_NO_POOL_KERNEL) && whole_range && (aligned || !fast) && fits) variant = 4;
+        // (the fast pool kernel orders a shadow ray's spheres by their centres' projections: disjoint spheres only)
+        if (((p->flags >> 8) & 0xffu) == 0u && !(p->flags & MC_PT_NO_POOL_KERNEL) && whole_range && (aligned || !fast) && fits &&
+            (!fast || a.scene.spheres_disjoint))
+            variant = 4;
     }
     // Lane-regrouping scheduler (pathtrace_regroup.h): slab scenes whose materials are all 1..3 (any other code makes the
     // shader re-trace an unchanged ray, which only the round-synchronous loop reproduces) within its packed-field limits.

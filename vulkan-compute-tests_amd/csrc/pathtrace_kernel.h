@@ -77,7 +77,9 @@ struct SceneArgs {
     const float* d_obj;
     const uint32_t* d_emissive;
     uint32_t n_emissive;
-    uint32_t pad2;
+    // Fast math, slab scenes: non-zero when the three spheres are pairwise disjoint with a margin (pathtrace.hip): the order of
+    // two spheres along any ray is then the order of their centres' projections (shadow_visible_disjoint)
+    uint32_t spheres_disjoint;
     uint32_t pad3, pad4;
 };
 
@@ -451,6 +453,36 @@ __device__ __forceinline__ bool shadow_reaches_sphere(const HotSlab& h, v3 o, v3
     if (li == 2) return dd[2] < dd[0] && dd[2] < dd[1] && dd[2] < h.inf;
     if (li == 1) return dd[1] < dd[0] && !(dd[2] < dd[1]) && dd[1] < h.inf;
     return !(dd[1] < dd[0]) && !(dd[2] < dd[0]) && dd[0] < h.inf;
+}
+
+// The same question — "is sphere li the nearest thing the shadow ray hits?" (:420) — for pairwise DISJOINT spheres (host-proved,
+// SceneArgs::spheres_disjoint) in fast math, WITHOUT a square root (a v_sqrt_f32 among other instructions costs ~12 issue cycles,
+// profiles/r03_valu_microbench7.txt; the three root blocks were a fifth of the diffuse bounce):
+//  * which root of sphere k the loop of :319-:327 would keep follows from comparing squares.  With e = b - eps: the near root
+//    b - sqrt(det) exceeds eps iff e > 0 and e^2 > det; otherwise the far root b + sqrt(det) exceeds eps iff e > 0 or det > e^2.
+//    So sphere k yields a hit iff det >= 0 and (e > 0 or det > e^2);
+//  * the parameter intervals [b - sqrt(det), b + sqrt(det)] in which a line runs inside two disjoint spheres are disjoint, so the
+//    kept root of one sphere lies before the kept root of another iff its b (the interval's midpoint) is the smaller one — also when
+//    the origin lies inside one of them (its kept root is then the END of an interval around 0 and every other interval that counts
+//    lies beyond it).
+// Sphere li is the nearest hit iff it yields a hit and no other sphere that yields a hit has a smaller b.  In exact arithmetic these are
+// the decisions of shadow_reaches_sphere; in fp32 they differ where a root lies within rounding of eps or a ray grazes a sphere.
+__device__ __forceinline__ bool shadow_visible_disjoint(const HotSlab& h, v3 d, int li, const v3* xoc, const float* occ) {
+    MC_PT_DECISION_FP
+    float b[3];
+    bool hit[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        b[i] = dot(xoc[i], d);                                               // :318
+        const float det = (b[i] * b[i] - occ[i]) + h.r2[i];
+        const float e = b[i] - h.eps;
+        hit[i] = !(det < 0.0f) && (e > 0.0f || det > e * e);
+    }
+    bool vis = hit[li];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        if (i != li) vis = vis && !(hit[i] && b[i] < b[li]);
+    return vis;
 }
 
 // ---- closed-box kernels (fast math only, Box = true) ---------------------------------------------------------------------

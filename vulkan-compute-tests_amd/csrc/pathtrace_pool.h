@@ -242,7 +242,10 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                         v3 le{ls[4], ls[5], ls[6]};
                         float cos_a_max;
                         v3 l = light_sample_direction<Fast>(xoc[i], occ[i], hot.r2[i], rnd, cos_a_max);   // :408-:413
-                        if (shadow_reaches_sphere<Fast>(hot, x, l, i, xoc[i], occ)) {                      // :420
+                        bool lit;                                                                          // :420
+                        if constexpr (Fast) lit = shadow_visible_disjoint(hot, l, i, xoc, occ);            // (the host selects this kernel for disjoint spheres)
+                        else lit = shadow_reaches_sphere<Fast>(hot, x, l, i, xoc[i], occ);
+                        if (lit) {
                             if constexpr (Fast) {
                                 const float scale = __builtin_fmaxf(dot(l, nl), 0.0f) * (2.0f - (cos_a_max + cos_a_max));   // :421-:422
                                 rad = rad + (accmat * le) * scale;
