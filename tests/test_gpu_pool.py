@@ -1,7 +1,9 @@
 """The sample-pool path tracer kernel (csrc/pathtrace_pool.h; MC_PT_MATH_FAST, closed-box scenes, whole sample ranges, tiles that
-keep the whole image's wave tiles).  Every sample's arithmetic is the round-synchronous closed-box kernel's; what differs is the
-order in which a pixel's fp32 contributions are added.  So: (1) against that kernel the storage buffer agrees to the last few
-ulps except where a rounding forks a path (different inlining contexts contract differently), (2) against the oracle it obeys
+keep the whole image's wave tiles).  Every sample follows the round-synchronous closed-box kernel's arithmetic except where the pool
+kernel uses a cheaper equivalent form (|c - x|^2 - r^2 formed once per bounce, shadow rays decided by comparing squares, a wall
+bounce as a signed permutation), and a pixel's fp32 contributions are added in another order.  So: (1) against that kernel the storage
+buffer agrees to the last few ulps except where a rounding forks a path (a few per cent of the pixels at these sample counts, each by at
+most one sample's weight), (2) against the oracle it obeys
 the fast-math tolerance, (3) it is deterministic and tiling-invariant bit for bit, (4) everything outside its domain runs the
 round-synchronous kernels exactly as before.
 The STRICT pool kernel keeps a per-path accrad and adds accrad / spp in sample order through a result ring in LDS: it must be
@@ -28,8 +30,10 @@ def test_pool_kernel_agrees_with_the_round_synchronous_kernel(ctx, B, W, H, spp,
     d = np.abs(pool - rounds)
     assert np.isfinite(pool).all()
     # a reassociated sum of spp x ~10 fp32 terms: a few 1e-5 of an 8-bit unit; a forked sample moves ONE pixel by up to 255 / spp
-    assert d.mean() <= 2e-3, d.mean()
-    assert (d > 1e-2).mean() <= 2e-3, (d > 1e-2).mean()
+    # (a near-tie decided the other way by a differently associated discriminant: under 3 % of the components, no drift of the mean)
+    assert d.mean() <= 5e-3, d.mean()
+    assert (d > 1e-2).mean() <= 3e-2, (d > 1e-2).mean()
+    assert abs((pool - rounds).mean()) <= 2e-3, (pool - rounds).mean()
 
 
 def test_pool_kernel_is_deterministic_and_tiling_invariant(ctx, B):

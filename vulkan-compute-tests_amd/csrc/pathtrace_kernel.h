@@ -256,6 +256,15 @@ struct WaveTime {};
 #ifndef MC_PT_FAST_PLANES_ONE_RCP   // fast math: one division for the three slab tests (intersect_slab)
 #define MC_PT_FAST_PLANES_ONE_RCP 1
 #endif
+#ifndef MC_PT_EXP_G
+#define MC_PT_EXP_G 1
+#endif
+#ifndef MC_PT_EXP_PID
+#define MC_PT_EXP_PID 1
+#endif
+#ifndef MC_PT_EXP_OCR
+#define MC_PT_EXP_OCR 1
+#endif
 
 constexpr float kEps = 1e-4f, kTriEps = 1e-7f, kInf = 1e20f;   // pathTracer.comp:103-105
 constexpr float kPi = 3.141592653589793f;                       // :102
@@ -359,7 +368,7 @@ struct HotSlab {
 // Closed (fast math, SceneArgs::box_ok, origin inside the box): the nearest facing plane IS a hit — the |d_a| > 1e-7 / t < 1e20
 // tests of :119 / :336 can only fail for a ray that runs along a wall it starts on to within 1e-7, or a NaN ray (which then
 // gathers nothing: every later comparison with its NaN t is false) — so they and the final "anything hit?" select are dropped.
-template <bool Fast, bool Closed = false>
+template <bool Fast, bool Closed = false, bool OccR2 = false>   // OccR2: occ[i] holds |c_i - o|^2 - r_i^2 (fast math)
 __device__ __forceinline__ int intersect_slab(const HotSlab& h, v3 o, v3 d, float& t_out, bool shadow_skip_planes,
                                               const float* occ = nullptr,     // occ[i] = dot(c_i - o, c_i - o) and
                                               const v3* oc_at_o = nullptr) {  // oc_at_o[i] = c_i - o if the caller has them
@@ -382,12 +391,15 @@ __device__ __forceinline__ int intersect_slab(const HotSlab& h, v3 o, v3 d, floa
             num[a] = (pos ? h.W_pos[a] : h.W_negm[a]) - oa; den[a] = da; pid[a] = pos ? 2 * a + 1 : 2 * a;
         }
         float bn = num[0], bd = den[0];
-        int bid = pid[0];
+        int bid = MC_PT_EXP_PID ? 1 : pid[0];
 #pragma unroll
         for (int a = 1; a < 3; a++) {
             const bool nearer = __builtin_fabsf(num[a]) * __builtin_fabsf(bd) < __builtin_fabsf(bn) * __builtin_fabsf(den[a]);
-            bn = nearer ? num[a] : bn; bd = nearer ? den[a] : bd; bid = nearer ? pid[a] : bid;
+            bn = nearer ? num[a] : bn; bd = nearer ? den[a] : bd; bid = nearer ? (MC_PT_EXP_PID ? 2 * a + 1 : pid[a]) : bid;
         }
+        // (the winner's id 2a + (d_a > 0): the odd id of its axis, less the sign bit of its d_a — two selects of constants and two
+        // integer operations instead of three selects, two ORs and two selects of the ids)
+        if (MC_PT_EXP_PID) bid ^= (int)(dm::as_uint(bd) >> 31);
         const float dd = dm::fdiv<Fast>(bn, bd);
         if constexpr (Closed) { t = dd; id = bid; }
         else if (__builtin_fabsf(bd) > h.tri_eps && dd < t) { t = dd; id = bid; }
@@ -405,7 +417,7 @@ __device__ __forceinline__ int intersect_slab(const HotSlab& h, v3 o, v3 d, floa
     for (int i = 0; i < 3; i++) {
         v3 oc = oc_at_o ? oc_at_o[i] : v3{h.c[i][0], h.c[i][1], h.c[i][2]} - o;   // :317
         float b = dot(oc, d);                                                // :318
-        float det = (b * b - (occ ? occ[i] : dot(oc, oc))) + h.r2[i];
+        float det = OccR2 ? b * b - occ[i] : (b * b - (occ ? occ[i] : dot(oc, oc))) + h.r2[i];
         if (!(det < 0.0f)) {                                                 // :319
             float sq = dm::fsqrt<Fast>(det);
             float dd = b - sq;                                               // :322,324
@@ -467,6 +479,7 @@ __device__ __forceinline__ bool shadow_reaches_sphere(const HotSlab& h, v3 o, v3
 //    lies beyond it).
 // Sphere li is the nearest hit iff it yields a hit and no other sphere that yields a hit has a smaller b.  In exact arithmetic these are
 // the decisions of shadow_reaches_sphere; in fp32 they differ where a root lies within rounding of eps or a ray grazes a sphere.
+template <bool OccR2>   // OccR2: occ[i] holds |c_i - x|^2 - r_i^2
 __device__ __forceinline__ bool shadow_visible_disjoint(const HotSlab& h, v3 d, int li, const v3* xoc, const float* occ) {
     MC_PT_DECISION_FP
     float b[3];
@@ -474,7 +487,7 @@ __device__ __forceinline__ bool shadow_visible_disjoint(const HotSlab& h, v3 d, 
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         b[i] = dot(xoc[i], d);                                               // :318
-        const float det = (b[i] * b[i] - occ[i]) + h.r2[i];
+        const float det = OccR2 ? b[i] * b[i] - occ[i] : (b[i] * b[i] - occ[i]) + h.r2[i];
         const float e = b[i] - h.eps;
         hit[i] = !(det < 0.0f) && (e > 0.0f || det > e * e);
     }
@@ -614,6 +627,24 @@ template <bool Fast> __device__ __forceinline__ v3 camera_ray(const PTArgs& a, u
 template <bool Fast> __device__ __forceinline__ v3 light_sample_direction(v3 xc, float xcc, float lr2, v3 rnd, float& cos_a_max) {
     const float inv_len = dm::inversesqrt<Fast>(xcc);
     v3 sw = xc * inv_len;                                     // :409 normalize(xc)
+    if constexpr (Fast && MC_PT_EXP_G) {
+        // The tangents are left UNNORMALISED — t1 = cross(axis, sw) (tangent_u before its scaling), t2 = cross(sw, t1), both of
+        // length k = sqrt(q^2 + sw.z^2) — and sin_a / k is formed as one factor: sqrt(A / B) = A * rsq(A * B) with A = sin_a^2 =
+        // 1 - cos_a^2, B = k^2: one transcendental where 1 / k and sin_a took two (each ~12 issue cycles among other instructions,
+        // profiles/r03_valu_microbench7.txt).  A is kept above zero: rnd.x below ~1e-5 rounds cos_a to 1 and 0 * rsq(0) is a NaN.
+        const bool sel = __builtin_fabsf(sw.x) > 0.1f;
+        const float q = sel ? sw.x : sw.y;
+        const float B = __builtin_fmaf(q, q, sw.z * sw.z);
+        cos_a_max = dm::fsqrt<true>(1.0f - lr2 * (inv_len * inv_len));        // :410
+        const float cos_a = (1.0f - rnd.x) + rnd.x * cos_a_max;               // :411
+        const float A = __builtin_fmaxf(1.0f - cos_a * cos_a, 1e-30f);
+        const float g = A * dm::inversesqrt<true>(A * B);
+        const v3 t1{sel ? sw.z : 0.0f, sel ? 0.0f : -sw.z, sel ? -q : q};
+        const v3 t2 = cross(sw, t1);
+        float sphi, cphi;
+        dm::sincos_angle<true>(0.0f, rnd.y, sphi, cphi);                      // :412
+        return (t1 * (cphi * g) + t2 * (sphi * g)) + sw * cos_a;              // :413
+    }
     v3 su = tangent_u<Fast>(sw);
     v3 sv = cross(sw, su);
     // :410; fast: 1 / |xc|^2 is the square of the 1 / |xc| above (one multiply instead of a v_rcp_f32)

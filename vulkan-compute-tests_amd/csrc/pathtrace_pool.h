@@ -71,6 +71,9 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
         r[8] = o[4]; r[9] = o[5]; r[10] = o[6]; r[11] = p;
     }
     __syncthreads();
+    // fast math: the sphere tests of a bounce (three of the shadow ray, three of the next ray, all from the hit point x) read
+    // |c_i - x|^2 - r_i^2, formed once, instead of each adding r_i^2 to its b^2 - |c_i - x|^2
+    constexpr bool kOccR2 = Fast && MC_PT_EXP_OCR;
     constexpr uint32_t TW = WaveTile<S>::w, TH = WaveTile<S>::h, Ring = 2u * (uint32_t)S, RRing = kPoolResultBatches * (uint32_t)S;
     HotSlab hot;
     hot.load<MC_PT_POOL_HOT_VGPR>(a.scene);   // (uniform operands: this kernel has no vector registers to spare for copies)
@@ -162,8 +165,11 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                 v3 oc0[3];
                 float occ0[3], ct;
 #pragma unroll
-                for (int i = 0; i < 3; i++) { oc0[i] = v3{a.cam_oc[i][0], a.cam_oc[i][1], a.cam_oc[i][2]}; occ0[i] = a.cam_occ[i]; }
-                int cid = intersect_slab<Fast, Fast>(hot, a.lc, crd, ct, false, occ0, oc0);
+                for (int i = 0; i < 3; i++) {
+                    oc0[i] = v3{a.cam_oc[i][0], a.cam_oc[i][1], a.cam_oc[i][2]};
+                    occ0[i] = kOccR2 ? a.cam_occ[i] - hot.r2[i] : a.cam_occ[i];
+                }
+                int cid = intersect_slab<Fast, Fast, kOccR2>(hot, a.lc, crd, ct, false, occ0, oc0);
                 // nothing to trace: a pixel outside the tile, a sample beyond the range; a camera ray that misses everything (:369)
                 // gathers nothing either
                 if (!(g.valid && samp < a.sample_end)) cid = -1;
@@ -203,6 +209,9 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                 v3 xoc[3];                                                        // c_i - x (:317 at the next depth, :408 now)
 #pragma unroll
                 for (int i = 0; i < 3; i++) { xoc[i] = v3{hot.c[i][0], hot.c[i][1], hot.c[i][2]} - x; occ[i] = dot(xoc[i], xoc[i]); }
+                float xcc[3];                                                     // |c_i - x|^2 itself (:410 needs it)
+#pragma unroll
+                for (int i = 0; i < 3; i++) { xcc[i] = occ[i]; if constexpr (kOccR2) occ[i] = occ[i] - hot.r2[i]; }
                 const float4* obj = reinterpret_cast<const float4*>(lds_obj + kPoolRecordStride * (uint32_t)id);   // per-lane fetch
                 const float4 o0 = obj[0], o1 = obj[1];
                 const bool is_sphere = id >= 6;
@@ -241,9 +250,9 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                         const float* ls = a.scene.obj + 12 * (6 + i);
                         v3 le{ls[4], ls[5], ls[6]};
                         float cos_a_max;
-                        v3 l = light_sample_direction<Fast>(xoc[i], occ[i], hot.r2[i], rnd, cos_a_max);   // :408-:413
+                        v3 l = light_sample_direction<Fast>(xoc[i], xcc[i], hot.r2[i], rnd, cos_a_max);   // :408-:413
                         bool lit;                                                                          // :420
-                        if constexpr (Fast) lit = shadow_visible_disjoint(hot, l, i, xoc, occ);            // (the host selects this kernel for disjoint spheres)
+                        if constexpr (Fast) lit = shadow_visible_disjoint<kOccR2>(hot, l, i, xoc, occ);            // (the host selects this kernel for disjoint spheres)
                         else lit = shadow_reaches_sphere<Fast>(hot, x, l, i, xoc[i], occ);
                         if (lit) {
                             if constexpr (Fast) {
@@ -271,7 +280,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                 key++;
                 go = key != kend;                                                 // :367 depth limit
                 if (go) {
-                    id = intersect_slab<Fast, Fast>(hot, ro, rd, t, false, occ, xoc);
+                    id = intersect_slab<Fast, Fast, kOccR2>(hot, ro, rd, t, false, occ, xoc);
                     go = id >= 0;                                                 // :369
                 }
                 if (go) {                                                         // the next bounce's random numbers and roulette
