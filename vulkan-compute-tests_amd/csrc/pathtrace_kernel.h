@@ -669,22 +669,27 @@ template <bool Fast, bool Unit> __device__ __forceinline__ v3 cosine_bounce(v3 w
     return Fast ? normalize_unit_combination<Fast, Unit>((u * (c1 * r2s) + v * (s1 * r2s)) + w * dm::fsqrt<Fast>(1.0f - r2))
                 : normalize_unit_combination<Fast, Unit>(((u * c1) * r2s + (v * s1) * r2s) + w * dm::fsqrt<Fast>(1.0f - r2));   // :428
 }
-// The same bounce around the inward normal of an axis-aligned WALL of a closed box (fast math): w = sigma * e_a, so the basis
-// of :427 is two signed axis vectors and :428's combination is a signed permutation of (c1 r2s, s1 r2s, sqrt(1 - r2)) — worked out
-// from tangent_u / cross above for the three axes; every component is the one non-zero term of the general form (its other two terms
-// are products with exact zeros, its factor 1/|..| is v_rsq_f32(1) = 1), i.e. the same values, without the basis: no v_rsq_f32, no
-// cross product, no 3 x 3 combination.  `id` = the wall's slab id 2a + (normal is +e_a); a hit wall faces the ray (:119), so
-// nl = -n and sigma is negative exactly for the odd ids.
-__device__ __forceinline__ v3 cosine_bounce_wall(int id, v3 rnd) {
-    const float r2s = dm::fsqrt<true>(rnd.y);
+// The same bounce around the inward normal of an axis-aligned WALL of a slab scene: w = sigma * e_a, so the basis of :427 is two
+// signed axis vectors — u = normalize(cross(axis, w)) has one component -+sigma and two zeros, its length factor is the (correctly
+// rounded, or v_rsq_f32's) 1 / sqrt(1) = 1, v = cross(w, u) likewise — and :428's combination ((u*c1)*r2s + (v*s1)*r2s) + w*C is a
+// signed permutation of (c1*r2s, s1*r2s, C = sqrt(1 - r2)): every component is the one non-zero term of that expression plus two
+// products with exact zeros, i.e. the SAME VALUE (worked out from tangent_u / cross for the three axes below), without the basis:
+// no reciprocal square root, no cross products, no 3 x 3 combination.  Strict mode then applies :428's normalize to it as before.
+// (Only the sign of a component that is itself a zero — rnd.y = 1, or a sine / cosine of exactly 0 — can differ from the general
+// form's; such a component multiplies t and is added to a non-zero coordinate, or fails the |d_a| > 1e-7 test of :119.)
+// `id` = the wall's slab id 2a + (normal is +e_a); a hit wall faces the ray (:119: dot(d, n) > 0), so nl = -n and sigma is
+// negative exactly for the odd ids.   a = 0: (sC, B, -sA)   a = 1: (B, sC, sA)   a = 2: (B, -sA, sC)   with sX = sigma * X.
+template <bool Fast> __device__ __forceinline__ v3 cosine_bounce_wall(int id, v3 rnd) {
+    const float r1 = (2.0f * kPi) * rnd.x, r2 = rnd.y, r2s = dm::fsqrt<Fast>(r2);   // :426
     float s1, c1;
-    dm::sincos_angle<true>(0.0f, rnd.x, s1, c1);
-    const float A = c1 * r2s, B = s1 * r2s, C = dm::fsqrt<true>(1.0f - rnd.y);
+    dm::sincos_angle<Fast>(r1, rnd.x, s1, c1);
+    const float A = c1 * r2s, B = s1 * r2s, C = dm::fsqrt<Fast>(1.0f - r2);
     const uint32_t sb = (uint32_t)id << 31;
     const float sC = dm::as_float(dm::as_uint(C) ^ sb), sA = dm::as_float(dm::as_uint(A) ^ sb);
     const float nsA = dm::as_float(dm::as_uint(sA) ^ 0x80000000u);
     const bool a0 = id < 2, a1 = id < 4;   // (a1 is read only where a0 is false)
-    return v3{a0 ? sC : B, a0 ? B : (a1 ? sC : nsA), a0 ? nsA : (a1 ? sA : sC)};
+    const v3 d{a0 ? sC : B, a0 ? B : (a1 ? sC : nsA), a0 ? nsA : (a1 ? sA : sC)};
+    return normalize_unit_combination<Fast, true>(d);                                // :428
 }
 
 // Mirror / glass bounce in the fast slab form (:432-:447): every outcome is rd*alpha + n*beta — reflection (1, -2 dot(n, rd)),

@@ -43,7 +43,7 @@ namespace mc {
 namespace pt {
 
 constexpr uint32_t kPoolEntryFloats = 8;     // {rd.x, rd.y, rd.z, t | id (-1: nothing to trace), key0 = samp * maxDepth, rnd.x, rnd.y of key0}
-constexpr uint32_t kPoolRecordStride = 16;   // floats per staged record: {geo.xyz, p (fast: 1 / p) | colour.rgb, material + 256 * emits | emission.xyz, p}
+constexpr uint32_t kPoolRecordStride = 16;   // floats per staged record: {geo.xyz, p (fast: 1 / p) | colour.rgb, material + 256 * emits | emission.xyz, RN(1 / p) (fast: p)}
 constexpr uint32_t kPoolRecordFloats = 9u * kPoolRecordStride;
 constexpr uint32_t kPoolStashFloats = 128u * kPoolEntryFloats;     // per wave: 64/S pixels x 2 batches x S entries
 constexpr uint32_t kPoolResultBatches = 4;                         // strict: result ring of 4 batches per pixel, 3 planes (x, y, z)
@@ -60,6 +60,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
     // and an "emits" flag as integer bits — the same fp32 operations on the same operands as evaluating them at every bounce.
     // Fast math: slot 3 holds v_rcp_f32(p), the factor :397's division multiplies by — formed once per block instead of once
     // per bounce and lane (a transcendental blocks the SIMD for 8 cycles); p itself, which :396 compares with, is in slot 11.
+    // Strict: slot 3 holds p and slot 11 the correctly rounded 1 / p that the short division of :397 starts from (dm::div3).
     if (threadIdx.x < 9u) {
         const float* o = a.scene.obj + 12u * threadIdx.x;
         float* r = lds_obj + kPoolRecordStride * threadIdx.x;
@@ -68,7 +69,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
         r[4] = o[8]; r[5] = o[9]; r[6] = o[10];
         const uint32_t emits = (o[4] != 0.0f || o[5] != 0.0f || o[6] != 0.0f) ? 256u : 0u;
         r[7] = dm::as_float((uint32_t)(int)__builtin_floorf(o[11] + 0.5f) | emits);
-        r[8] = o[4]; r[9] = o[5]; r[10] = o[6]; r[11] = p;
+        r[8] = o[4]; r[9] = o[5]; r[10] = o[6]; r[11] = Fast ? p : dm::rcp_short(p);
     }
     __syncthreads();
     // fast math: the sphere tests of a bounce (three of the shadow ray, three of the next ray, all from the hit point x) read
@@ -237,7 +238,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                 accmat = accmat * col;                                            // :392
                 const v3 rnd{rx, ry, 0.0f};                                       // :393 (drawn at the end of the previous bounce)
                 if constexpr (Fast) accmat = accmat * (key > krr ? p : 1.0f);     // :395, :397 (:396 was decided there too)
-                else if (key > krr) accmat = divs<Fast>(accmat, p);
+                else if (key > krr) accmat = divs_recip<Fast>(accmat, p, obj[2].w);
                 bool go = true;
                 {
                 ro = x;                                                           // :429, :434, :447
@@ -264,13 +265,9 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                             }
                         }
                     }
-                    if constexpr (Fast) {                                         // :426-:428
-                        // (uniform: no lane of the wave bounces off a diffuse SPHERE — the light — in almost every iteration)
-                        if (__ballot(is_sphere) == 0ull) rd = cosine_bounce_wall(id, rnd);
-                        else rd = cosine_bounce<Fast, true>(nl, rnd);
-                    } else {
-                        rd = cosine_bounce<Fast, true>(nl, rnd);
-                    }
+                    // :426-:428 (uniform: no lane of the wave bounces off a diffuse SPHERE — the light — in almost every iteration)
+                    if (__ballot(is_sphere) == 0ull) rd = cosine_bounce_wall<Fast>(id, rnd);
+                    else rd = cosine_bounce<Fast, true>(nl, rnd);
                     emissive = 0.0f;                                              // :429
                 } else {                                                          // :432 mirror, :437 glass (box_ok: 2 or 3)
                     if constexpr (Fast) rd = specular_bounce_fast(mat, rd, n, dot_n_rd, rnd.x, accmat);
@@ -288,7 +285,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                     rx = rn.x; ry = rn.y;
                     if (key > krr) {                                              // :395 depth > 5
                         const float4* nobj = reinterpret_cast<const float4*>(lds_obj + kPoolRecordStride * (uint32_t)id);
-                        go = !(rn.z >= nobj[2].w);                                // :396
+                        go = !(rn.z >= nobj[Fast ? 2 : 0].w);                     // :396
                         // a path the roulette ends has still gathered the emission of this hit (:391 precedes :396)
                         if (__ballot(!go && dm::as_uint(nobj[1].w) >= 256u) != 0ull) {
                             const float4 o2 = nobj[2];
