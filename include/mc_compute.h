@@ -187,6 +187,7 @@ int mc_pathtrace_render_rgba8(mc_context* ctx, const mc_pathtrace_params* p, con
  * every other scene takes the generic kernel. */
 #define MC_PT_SCENE_SLAB 1u
 #define MC_PT_SCENE_LIGHTS_INSIDE 2u
+#define MC_PT_SCENE_SPHERES_DISJOINT 4u   /* slab scenes: the three spheres are pairwise disjoint (the fast sample-pool kernel's premise) */
 int mc_pathtrace_scene_class(const float* planes, uint32_t n_planes, const float* spheres, uint32_t n_spheres,
                              uint32_t* out_class);
 

@@ -162,10 +162,20 @@ def test_scene_classification_host_logic(B, O):
     """mc_pathtrace_scene_class exposes the host analysis that selects the path tracer's exact specialisations (slab
     kernels; shadow rays that skip the walls).  The decisions below are the ones the GPU parity tests rely on
     (tests/test_gpu_scenes.py::test_shadow_ray_plane_skip_is_exact renders the same scenes against the oracle)."""
-    SLAB, INSIDE = B.PT_SCENE_SLAB, B.PT_SCENE_LIGHTS_INSIDE
+    SLAB, INSIDE, DISJOINT = B.PT_SCENE_SLAB, B.PT_SCENE_LIGHTS_INSIDE, B.PT_SCENE_SPHERES_DISJOINT
     P = O.DEFAULT_PLANES.copy().reshape(6, 12)
     S = O.DEFAULT_SPHERES.copy().reshape(3, 12)
-    assert B.pathtrace_scene_class(P, S) == SLAB | INSIDE           # the reference scene, pathtracerApp.h:14-39
+    assert B.pathtrace_scene_class(P, S) == SLAB | INSIDE | DISJOINT   # the reference scene, pathtracerApp.h:14-39
+    # bit 2: the three spheres pairwise disjoint with a margin (the fast sample-pool kernel's premise)
+    touch = S.copy(); touch[1, 0:3] = touch[0, 0:3] + np.float32([1.6, 0, 0])          # radii 0.8 + 0.8: tangent -> refused
+    assert B.pathtrace_scene_class(P, touch) & DISJOINT == 0
+    touch[1, 0] += np.float32(0.01)                                                     # 0.01 apart: clears 1e-3 (1 + 1.6)
+    assert B.pathtrace_scene_class(P, touch) & DISJOINT == DISJOINT
+    nested = S.copy(); nested[2, 0:3] = nested[1, 0:3]                                   # the light inside the glass sphere
+    assert B.pathtrace_scene_class(P, nested) & DISJOINT == 0
+
+    def cls(planes, spheres):   # (the cases below are about bits 0 and 1)
+        return B.pathtrace_scene_class(planes, spheres) & ~DISJOINT
 
     def light(**kw):
         s = S.copy()
@@ -173,28 +183,28 @@ def test_scene_classification_host_logic(B, O):
             s[2, {"x": 0, "y": 1, "z": 2, "r": 3}[k]] = v
         return s
     # margin = 16 sqrt(eps) * scale = 16 * 3.4527e-4 * 7.9 = 0.0436 (pathtrace.hip, lights_inside_box)
-    assert B.pathtrace_scene_class(P, light(y=1.75)) == SLAB | INSIDE     # 0.05 below the ceiling: clears the margin
-    assert B.pathtrace_scene_class(P, light(y=1.76)) == SLAB              # 0.04 below: inside the margin -> refused
-    assert B.pathtrace_scene_class(P, light(y=1.79)) == SLAB              # 0.01 below (taken in round 1; the sphere root of a
+    assert cls(P, light(y=1.75)) == SLAB | INSIDE     # 0.05 below the ceiling: clears the margin
+    assert cls(P, light(y=1.76)) == SLAB              # 0.04 below: inside the margin -> refused
+    assert cls(P, light(y=1.79)) == SLAB              # 0.01 below (taken in round 1; the sphere root of a
                                                                           # grazing shadow ray is only good to ~1e-2 there)
-    assert B.pathtrace_scene_class(P, light(y=1.95)) == SLAB              # pokes through the ceiling
-    assert B.pathtrace_scene_class(P, light(x=-2.45, r=0.15)) == SLAB     # touches the left wall
-    assert B.pathtrace_scene_class(P, light(y=3.5, r=0.3)) == SLAB        # outside the room
-    assert B.pathtrace_scene_class(P, light(r=0.0)) == SLAB               # degenerate radius
+    assert cls(P, light(y=1.95)) == SLAB              # pokes through the ceiling
+    assert cls(P, light(x=-2.45, r=0.15)) == SLAB     # touches the left wall
+    assert cls(P, light(y=3.5, r=0.3)) == SLAB        # outside the room
+    assert cls(P, light(r=0.0)) == SLAB               # degenerate radius
     dark = S.copy(); dark[2, 4:7] = 0
-    assert B.pathtrace_scene_class(P, dark) == SLAB                       # no emissive sphere: nothing to skip
+    assert cls(P, dark) == SLAB                       # no emissive sphere: nothing to skip
     two = S.copy(); two[0, 4:7] = (30, 20, 10); two[0, 1] = -1.0         # (as shipped it rests ON the floor: refused)
     on_floor = two.copy(); on_floor[0, 1] = S[0, 1]
-    assert B.pathtrace_scene_class(P, on_floor) == SLAB
-    assert B.pathtrace_scene_class(P, two) == SLAB | INSIDE               # every emissive sphere is checked
+    assert cls(P, on_floor) == SLAB
+    assert cls(P, two) == SLAB | INSIDE               # every emissive sphere is checked
     two[0, 1] = -1.9                                                      # ... the second light dips through the floor
-    assert B.pathtrace_scene_class(P, two) == SLAB
+    assert cls(P, two) == SLAB
     # camera outside the box (front wall moved in front of the pinhole at z = 7.4 - 0.035)
     near = P.copy(); near[5, 3] = 7.0
-    assert B.pathtrace_scene_class(near, S) == SLAB
+    assert cls(near, S) == SLAB
     # inverted box: the two x planes swapped offsets so that lo > hi
     inv = P.copy(); inv[0, 3] = -3.0
-    assert B.pathtrace_scene_class(inv, S) == SLAB
+    assert cls(inv, S) == SLAB
     # not an index-ordered axis-aligned box -> generic kernel
     perm = P[[2, 3, 0, 1, 4, 5]]
     assert B.pathtrace_scene_class(perm, S) == 0

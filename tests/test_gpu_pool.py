@@ -122,3 +122,56 @@ def test_strict_pool_kernel_tiles_of_any_alignment(ctx, B, O):
                                              row_stride=n * blk))
         rows = np.array([r for r in range(H) if (r // blk) % n == rank])
         assert np.array_equal(bits(t), bits(whole[rows])), rank
+
+
+def _scene(O):
+    return O.DEFAULT_PLANES.copy().reshape(6, 12), O.DEFAULT_SPHERES.copy().reshape(3, 12)
+
+
+def test_fast_pool_kernel_needs_disjoint_spheres(ctx, B, O):
+    """The fast pool kernel orders the spheres a shadow ray meets by the projections of their centres, which is the order of their
+    hits only for DISJOINT spheres (pathtrace_kernel.h, shadow_visible_disjoint): with two spheres pushed into each other the host
+    must take the round-synchronous closed-box kernel (same bits as MC_PT_NO_POOL_KERNEL), within the fast tolerance; the strict
+    pool kernel has no such premise and stays bit-identical."""
+    planes, spheres = _scene(O)
+    spheres[1, 0:3] = spheres[0, 0:3] + np.float32([0.9, 0.0, 0.3])   # the glass sphere cuts into the mirror sphere
+    W, H, spp = 96, 64, 64
+    fast = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST), planes=planes, spheres=spheres)
+    rounds = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, flags=B.PT_NO_POOL_KERNEL), planes=planes, spheres=spheres)
+    assert np.array_equal(bits(fast), bits(rounds))
+    strict = ctx.pathtrace(B.pathtrace_params(W, H, spp), planes=planes, spheres=spheres)
+    assert np.array_equal(bits(strict), bits(O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC)))
+    # and a hair's breadth apart they are disjoint for the host: the pool kernel runs (other bits than the round-synchronous kernel)
+    spheres[1, 0:3] = spheres[0, 0:3] + np.float32([1.7, 0.0, 0.0])
+    fast = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST), planes=planes, spheres=spheres)
+    rounds = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, flags=B.PT_NO_POOL_KERNEL), planes=planes, spheres=spheres)
+    assert not np.array_equal(bits(fast), bits(rounds))
+    d = fast[..., :3].astype(np.float64) - rounds[..., :3].astype(np.float64)
+    assert abs(d.mean()) < 0.05 and np.sqrt((d ** 2).mean()) < 1.0
+
+
+@pytest.mark.parametrize("case", ["light_is_sphere_0", "two_lights", "diffuse_sphere_and_mirror_wall"])
+def test_pool_kernel_scene_variants_within_tolerance(ctx, B, O, case):
+    """What the default scene does not exercise in the pool kernels: a light that is not the last sphere and two lights (the unrolled
+    light loop, shadow rays whose target is sphere 0 / 1), a diffuse non-emitting sphere (the general cosine bounce beside the wall
+    form, shadow rays that start ON an occluder) and a mirror wall (a specular bounce off a plane).  Fast within the small-size
+    tolerance of the oracle with libm, strict bit-identical."""
+    planes, spheres = _scene(O)
+    if case == "light_is_sphere_0":
+        spheres[[0, 2]] = spheres[[2, 0]]
+    elif case == "two_lights":
+        spheres[1, 4:7] = np.float32([40.0, 30.0, 20.0]); spheres[1, 8:11] = 0.0; spheres[1, 11] = 1.0; spheres[1, 3] = np.float32(0.3)
+    else:
+        spheres[0, 8:11] = np.float32([0.7, 0.5, 0.3]); spheres[0, 11] = 1.0
+        planes[4, 11] = 2.0; planes[4, 8:11] = np.float32(0.9)
+    W, H, spp = 96, 64, 256
+    assert B.pathtrace_scene_class(planes, spheres) == B.pathtrace_scene_class(*_scene(O))   # still a closed-box slab scene
+    strict = ctx.pathtrace(B.pathtrace_params(W, H, spp), planes=planes, spheres=spheres)
+    assert np.array_equal(bits(strict), bits(O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC)))
+    fast = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST), planes=planes, spheres=spheres)[..., :3].astype(np.float64)
+    ref = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_LIBM)[..., :3].astype(np.float64)
+    d = fast - ref
+    rmse = float(np.sqrt((d ** 2).mean()))
+    p999 = float(np.percentile(np.sqrt((d ** 2).sum(-1)), 99.9))
+    print(f"{case}: pool vs oracle(libm): rmse {rmse:.4f}  p99.9 L2 {p999:.3f}  mean diff {d.mean():+.5f}")
+    assert rmse <= 0.5 and p999 <= 4.0 and abs(d.mean()) < 0.05

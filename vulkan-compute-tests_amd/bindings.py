@@ -179,7 +179,7 @@ def tile_rows(p):
     return int(lib().mc_tile_rows(p.row_begin, p.row_end, p.row_block, p.row_stride))
 
 
-PT_SCENE_SLAB, PT_SCENE_LIGHTS_INSIDE = 1, 2
+PT_SCENE_SLAB, PT_SCENE_LIGHTS_INSIDE, PT_SCENE_SPHERES_DISJOINT = 1, 2, 4
 
 
 def pathtrace_scene_class(planes, spheres):

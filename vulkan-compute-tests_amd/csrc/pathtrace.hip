@@ -103,14 +103,28 @@ int choose_S(uint64_t pixels, uint32_t samples) {
 
 }  // namespace
 
+// The three spheres of a slab scene pairwise disjoint, with a margin far above fp32 rounding of the kernel's squared distances
+// (the fast sample-pool kernel orders the spheres a shadow ray meets by their centres' projections, shadow_visible_disjoint).
+static bool spheres_disjoint(const float* spheres) {
+    for (uint32_t i = 0; i < 3; i++)
+        for (uint32_t j = i + 1; j < 3; j++) {
+            const float* si = spheres + 12 * i;
+            const float* sj = spheres + 12 * j;
+            const double dx = (double)si[0] - sj[0], dy = (double)si[1] - sj[1], dz = (double)si[2] - sj[2];
+            const double radii = std::fabs((double)si[3]) + std::fabs((double)sj[3]);
+            if (!(std::sqrt(dx * dx + dy * dy + dz * dz) - radii > 1e-3 * (1.0 + radii))) return false;   // also NaN
+        }
+    return true;
+}
+
 // Host-side scene analysis behind mc_pathtrace_scene_class (no device involved): bit 0 = the scene takes the slab
-// kernels, bit 1 = its shadow rays skip the plane tests.
+// kernels, bit 1 = its shadow rays skip the plane tests, bit 2 = its three spheres are pairwise disjoint.
 uint32_t pathtrace_scene_class(const float* planes, uint32_t n_planes, const float* spheres, uint32_t n_spheres) {
     PTArgs a;
     std::memset(&a, 0, sizeof(a));
     set_camera(a);
     if (!analyse_slabs(planes, n_planes, n_spheres, a.scene)) return 0u;
-    return 1u | (lights_inside_box(a.scene, spheres, n_spheres, a.cam_o, a.lc) ? 2u : 0u);
+    return 1u | (lights_inside_box(a.scene, spheres, n_spheres, a.cam_o, a.lc) ? 2u : 0u) | (spheres_disjoint(spheres) ? 4u : 0u);
 }
 
 int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
@@ -174,16 +188,7 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
                 const float c = a.scene.obj[12 * i + k];
                 if (!(c >= 0.0f && c <= 1.0f)) a.scene.emit_skip_ok = 0u;     // also rejects NaN
             }
-        // the three spheres pairwise disjoint, with a margin far above fp32 rounding of the kernel's squared distances
-        a.scene.spheres_disjoint = 1u;
-        for (uint32_t i = 0; i < 3; i++)
-            for (uint32_t j = i + 1; j < 3; j++) {
-                const float* si = spheres + 12 * i;
-                const float* sj = spheres + 12 * j;
-                const double dx = (double)si[0] - sj[0], dy = (double)si[1] - sj[1], dz = (double)si[2] - sj[2];
-                const double gap = std::sqrt(dx * dx + dy * dy + dz * dz) - (std::fabs((double)si[3]) + std::fabs((double)sj[3]));
-                if (!(gap > 1e-3 * (1.0 + std::fabs((double)si[3]) + std::fabs((double)sj[3])))) a.scene.spheres_disjoint = 0u;   // also NaN
-            }
+        a.scene.spheres_disjoint = spheres_disjoint(spheres) ? 1u : 0u;
         // closed-box fast kernel: no ray may ever leave the box (pathtrace_kernel.h, intersect_box)
         a.scene.box_ok = (a.scene.nee_skip_planes && a.scene.materials_known && !glass_wall && a.scene.emit_skip_ok) ? 1u : 0u;
     } else {      // any other scene: device buffer [records | emissive sphere indices], staged into LDS by the kernel
