@@ -35,6 +35,9 @@
 #ifndef MC_PT_POOL_WAVES
 #define MC_PT_POOL_WAVES 7   // waves per SIMD the register budget is set for (72 VGPRs; 6: 18.29 ms, 7: 18.11, 8: 18.68 at K2)
 #endif
+#ifndef MC_PT_POOL_KEEP_VALID   // the pixel's validity kept across the loop (a lane mask) instead of re-derived per batch
+#define MC_PT_POOL_KEEP_VALID 1
+#endif
 #ifndef MC_PT_POOL_HOT_VGPR
 #define MC_PT_POOL_HOT_VGPR false
 #endif
@@ -98,6 +101,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
     };
     // my pixel's coordinates (:349) stay: the RNG key of every bounce needs them; so does the base of its stash
     uint32_t gx, gy;
+    bool pixel_valid;         // my pixel lies in the image and in the tile (:348)
     float* const gstash = lds_dyn + kPoolRecordFloats + (threadIdx.x >> 6) * pool_wave_lds_floats<Fast>() +
                           ((threadIdx.x & 63u) / (uint32_t)S) * (Ring * kPoolEntryFloats);
     // strict: my pixel's result ring [3][RRing] (x, y, z planes) behind the wave's stash
@@ -108,7 +112,8 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
         gx = blockIdx.x * (2u * TW) + (wave & 1u) * TW + pix % TW;
         const uint32_t ty = blockIdx.y * (2u * TH) + (wave >> 1) * TH + pix / TW;
         const uint32_t srow = tile_row_to_storage(ty, a.row_begin, a.row_block, a.row_stride);
-        gy = a.H - 1u - ((gx < a.W && srow < a.row_end) ? srow : 0u);
+        pixel_valid = gx < a.W && srow < a.row_end;
+        gy = a.H - 1u - (pixel_valid ? srow : 0u);
     }
     const uint32_t n_batches = (a.sample_end - a.sample_begin + (uint32_t)S - 1u) / (uint32_t)S;
     uint32_t batch = 0u;      // wave-uniform: batches produced; every pixel's stash has received batch * S entries
@@ -160,7 +165,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
             }
             // one more batch when a pixel wants more rays than it has — and every pixel's ring has room for S more
             if (want) {
-                const Lane g = my_lane(true);
+                const Lane g = my_lane(MC_PT_POOL_KEEP_VALID ? false : true);
                 const uint32_t samp = a.sample_begin + batch * (uint32_t)S + g.sub;
                 const v3 crd = camera_ray<Fast>(a, gx, gy, samp);
                 v3 oc0[3];
@@ -173,7 +178,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                 int cid = intersect_slab<Fast, Fast, kOccR2>(hot, a.lc, crd, ct, false, occ0, oc0);
                 // nothing to trace: a pixel outside the tile, a sample beyond the range; a camera ray that misses everything (:369)
                 // gathers nothing either
-                if (!(g.valid && samp < a.sample_end)) cid = -1;
+                if (!((MC_PT_POOL_KEEP_VALID ? pixel_valid : g.valid) && samp < a.sample_end)) cid = -1;
                 if constexpr (!Fast) {   // such a sample's result is a zero (adding +0 changes no bit of the sum)
                     const uint32_t slot = (batch * (uint32_t)S + g.sub) & (RRing - 1u);
                     if (cid < 0) { gres[slot] = 0.0f; gres[RRing + slot] = 0.0f; gres[2u * RRing + slot] = 0.0f; }
