@@ -124,6 +124,32 @@ def test_strict_pool_kernel_tiles_of_any_alignment(ctx, B, O):
         assert np.array_equal(bits(t), bits(whole[rows])), rank
 
 
+def test_strict_pool_kernel_continues_an_accumulator(ctx, B, O):
+    """The samps.x protocol (pathTracer.comp:451-453) through the strict pool kernel: ranges that start and end inside batches, a
+    one-sample range, the last range applying :453 — every stage bit-identical to the oracle's accumulator at that stage and the
+    final image to a one-launch render; also on an interleaved tile (the multi-GPU checkpoint case)."""
+    W, H, spp = 40, 24, 53
+    cuts = [0, 7, 8, 30, 52, 53]
+    acc = ref = None
+    for b, e in zip(cuts[:-1], cuts[1:]):
+        acc = ctx.pathtrace(B.pathtrace_params(W, H, spp, sample_begin=b, sample_end=e), acc=acc)
+        ref = O.pathtrace(W, H, spp, math_mode=O.MATH_MC, sample_begin=b, sample_end=e, acc=ref)
+        assert np.array_equal(bits(acc), bits(ref)), (b, e)
+    assert np.array_equal(bits(acc), bits(ctx.pathtrace(B.pathtrace_params(W, H, spp))))
+    # the same through the round-synchronous kernels (what ran before the pool kernel took sample ranges)
+    acc2 = None
+    for b, e in zip(cuts[:-1], cuts[1:]):
+        acc2 = ctx.pathtrace(B.pathtrace_params(W, H, spp, sample_begin=b, sample_end=e, flags=B.PT_NO_POOL_KERNEL), acc=acc2)
+    assert np.array_equal(bits(acc2), bits(acc))
+    blk = B.lib().mc_row_block()
+    whole = O.pathtrace(W, H, spp, math_mode=O.MATH_MC)
+    kw = dict(row_begin=blk, row_end=H, row_block=blk, row_stride=2 * blk)
+    t = ctx.pathtrace(B.pathtrace_params(W, H, spp, sample_begin=0, sample_end=20, **kw))
+    t = ctx.pathtrace(B.pathtrace_params(W, H, spp, sample_begin=20, sample_end=spp, **kw), acc=t)
+    rows = np.array([r for r in range(H) if (r // blk) % 2 == 1])
+    assert np.array_equal(bits(t), bits(whole[rows]))
+
+
 def _scene(O):
     return O.DEFAULT_PLANES.copy().reshape(6, 12), O.DEFAULT_SPHERES.copy().reshape(3, 12)
 

@@ -233,7 +233,9 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
         // wave tiles are those of the whole image — a wave's pixels, hence its schedule, are then the same for every tiling:
         // N-GPU output == 1-GPU output, bit for bit.  The strict variant adds in sample order whatever the tile.
         const uint32_t th = 2u;   // WaveTile<16>::h
-        const bool whole_range = p->sample_begin == 0u && p->sample_end == p->spp;
+        // (strict: any sample range — the ordered sum continues from the stored accumulator exactly as the round-synchronous kernels'
+        // does; fast: whole ranges only, its per-lane partial sums would make a progressive render differ from a one-launch one)
+        const bool whole_range = !fast || (p->sample_begin == 0u && p->sample_end == p->spp);
         const bool aligned = p->row_begin % th == 0u && (a.row_block == 0u || (a.row_block % th == 0u && a.row_stride % th == 0u)) &&
                              (p->row_end % th == 0u || p->row_end == p->height);
         const bool fits = p->max_depth >= 1u && (uint64_t)p->spp * p->max_depth < (1ull << 32) && p->width < (1u << 24);

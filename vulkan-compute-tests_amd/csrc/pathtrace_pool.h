@@ -121,6 +121,14 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
     // ---- the state of a lane's path, and the radiance its paths have gathered
     v3 ro{0, 0, 0}, rd{0, 0, 1}, accmat{1, 1, 1}, acc{0, 0, 0};   // acc: fast = this lane's partial sum; strict = the pixel's ordered sum
     v3 accrad{0, 0, 0};       // strict: the radiance of the current path (:391, :422)
+    if constexpr (!Fast) {
+        // strict: a later sample range continues the ordered sum the caller passes back in (the samps.x protocol, :451-:452) —
+        // every lane of the pixel starts from the stored value and adds the range's samples in order, as one launch would have
+        if (a.sample_begin > 0u) {
+            const Lane me = my_lane(true);
+            if (me.valid) { const float4 prev = a.out[(size_t)me.ty * a.W + gx]; acc = v3{prev.x, prev.y, prev.z}; }
+        }
+    }
     uint32_t cur = 0u;        // strict: index (within my pixel) of the sample this lane traces; its result slot is cur % RRing
     uint32_t committed = 0u;  // strict: samples of my pixel already added to acc (the same value in all S lanes)
     const float fspp = (float)a.spp;
