@@ -227,7 +227,7 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
     if (slab && a.scene.box_ok && !(p->flags & MC_PT_NO_BOX_KERNEL)) {
         const bool fast = p->math_mode == MC_PT_MATH_FAST;
         if (fast) variant = 3;   // the closed-box round-synchronous kernels (scene facts at compile time)
-        // The sample-pool kernels (pathtrace_pool.h): whole sample ranges only (the pixel sums are formed inside the launch), the
+        // The sample-pool kernels (pathtrace_pool.h): fast math whole sample ranges only (the pixel sums are formed inside the launch), the
         // automatic width; 16 lanes per pixel and batch (2 x 2 pixels per wave) for every image size — never a function of the tile.
         // Fast math adds a pixel's radiance in an order that depends on the wave's schedule, so it is selected only for tiles whose
         // wave tiles are those of the whole image — a wave's pixels, hence its schedule, are then the same for every tiling:
