@@ -43,8 +43,8 @@ int launch_fast(const PTArgs& a, int variant, int S, int prec, uint32_t tile_row
 
 #ifdef MC_PT_REGION_STATS
 // Diagnostic build (make stats): read and reset the per-region execution / active-lane counters of the fast kernels.
-extern "C" int mc_debug_pt_region_stats(unsigned long long* exec16, unsigned long long* lanes16) {
-    unsigned long long zero[16] = {0};
+extern "C" int mc_debug_pt_region_stats(unsigned long long* exec16, unsigned long long* lanes16) {   // (32 entries each)
+    unsigned long long zero[32] = {0};
     if (hipMemcpyFromSymbol(exec16, HIP_SYMBOL(mc::pt::g_region_exec), sizeof(zero)) != hipSuccess) return 3;
     if (hipMemcpyFromSymbol(lanes16, HIP_SYMBOL(mc::pt::g_region_lanes), sizeof(zero)) != hipSuccess) return 3;
     if (hipMemcpyToSymbol(HIP_SYMBOL(mc::pt::g_region_exec), zero, sizeof(zero)) != hipSuccess) return 3;

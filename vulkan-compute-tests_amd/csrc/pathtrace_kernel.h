@@ -161,8 +161,8 @@ __device__ __forceinline__ v3 rand01(uint32_t x, uint32_t y, uint32_t z) {
 // Diagnostic build only (make stats -> lib/libmc_compute_stats.so, tools/pt_region_stats.py): how often each code
 // region is executed by a wave and with how many active lanes — the divergence picture behind DESIGN.md §3.3.
 #ifdef MC_PT_REGION_STATS
-static __device__ unsigned long long g_region_exec[16];
-static __device__ unsigned long long g_region_lanes[16];
+static __device__ unsigned long long g_region_exec[32];
+static __device__ unsigned long long g_region_lanes[32];
 #ifdef MC_PT_REGION_TIME
 #define MC_REGION(r) do { } while (0)
 #define MC_ACCUM(r, value) do { } while (0)
@@ -261,6 +261,15 @@ struct WaveTime {};
 #endif
 #ifndef MC_PT_EXP_PID
 #define MC_PT_EXP_PID 1
+#endif
+#ifndef MC_PT_EXP_FRAME
+#define MC_PT_EXP_FRAME 1
+#endif
+#ifndef MC_PT_EXP_LIGHTHIT
+#define MC_PT_EXP_LIGHTHIT 1
+#endif
+#ifndef MC_PT_EXP_COLP
+#define MC_PT_EXP_COLP 1
 #endif
 #ifndef MC_PT_EXP_OCR
 #define MC_PT_EXP_OCR 1
@@ -368,7 +377,7 @@ struct HotSlab {
 // Closed (fast math, SceneArgs::box_ok, origin inside the box): the nearest facing plane IS a hit — the |d_a| > 1e-7 / t < 1e20
 // tests of :119 / :336 can only fail for a ray that runs along a wall it starts on to within 1e-7, or a NaN ray (which then
 // gathers nothing: every later comparison with its NaN t is false) — so they and the final "anything hit?" select are dropped.
-template <bool Fast, bool Closed = false, bool OccR2 = false>   // OccR2: occ[i] holds |c_i - o|^2 - r_i^2 (fast math)
+template <bool Fast, bool Closed = false, bool OccR2 = false, int StatsBase = -1>   // OccR2: occ[i] holds |c_i - o|^2 - r_i^2 (fast math)
 __device__ __forceinline__ int intersect_slab(const HotSlab& h, v3 o, v3 d, float& t_out, bool shadow_skip_planes,
                                               const float* occ = nullptr,     // occ[i] = dot(c_i - o, c_i - o) and
                                               const v3* oc_at_o = nullptr) {  // oc_at_o[i] = c_i - o if the caller has them
@@ -423,6 +432,7 @@ __device__ __forceinline__ int intersect_slab(const HotSlab& h, v3 o, v3 d, floa
         float b = dot(oc, d);                                                // :318
         float det = OccR2 ? b * b - occ[i] : (b * b - (occ ? occ[i] : dot(oc, oc))) + h.r2[i];
         if (!(det < 0.0f)) {                                                 // :319
+            if constexpr (StatsBase >= 0) MC_REGION(StatsBase + i);          // (diagnostic build: root block of sphere i)
             float sq = dm::fsqrt<Fast>(det);
             float dd = b - sq;                                               // :322,324
             if (dd <= h.eps) {                                               // :325
@@ -492,6 +502,9 @@ __device__ __forceinline__ bool shadow_visible_disjoint(const HotSlab& h, v3 d, 
     for (int i = 0; i < 3; i++) {
         b[i] = dot(xoc[i], d);                                               // :318
         const float det = OccR2 ? b[i] * b[i] - occ[i] : (b[i] * b[i] - occ[i]) + h.r2[i];
+        // (the ray is aimed INTO the light's cone, :408-:413: its line meets the light by construction and the root :319-:327 keep lies
+        // ahead — only det >= 0 is tested for it: the rim of the cone, where rounding decides, and a NaN direction, which must not pass)
+        if (MC_PT_EXP_LIGHTHIT && i == li) { hit[i] = det >= 0.0f; continue; }
         const float e = b[i] - h.eps;
         hit[i] = !(det < 0.0f) && (e > 0.0f || det > e * e);
     }
@@ -643,10 +656,22 @@ template <bool Fast> __device__ __forceinline__ v3 light_sample_direction(v3 xc,
         const float cos_a = (1.0f - rnd.x) + rnd.x * cos_a_max;               // :411
         const float A = __builtin_fmaxf(1.0f - cos_a * cos_a, 1e-30f);
         const float g = A * dm::inversesqrt<true>(A * B);
-        const v3 t1{sel ? sw.z : 0.0f, sel ? 0.0f : -sw.z, sel ? -q : q};
-        const v3 t2 = cross(sw, t1);
         float sphi, cphi;
         dm::sincos_angle<true>(0.0f, rnd.y, sphi, cphi);                      // :412
+        if (MC_PT_EXP_FRAME) {
+            // t1 = (z, 0, -x) or (0, -z, y) has a zero component and t2 = cross(sw, t1) = (-xy, B, -yz) or (B, -xy, -xz) carries B
+            // itself, so a t1 + b t2 + c sw needs no cross product: with m = the axis component (y or x), q the other one,
+            // cm = c - b m and sa = +-a:  special component = b B + c m,  the other two = sa z + q cm  and  -sa q + z cm.
+            const float a = cphi * g, b = sphi * g, c = cos_a;
+            const float m = sel ? sw.y : sw.x;
+            const float cm = __builtin_fmaf(-b, m, c);
+            const float sp = __builtin_fmaf(b, B, c * m);
+            const float sa = sel ? a : -a;
+            const float first = __builtin_fmaf(sa, sw.z, q * cm), lz = __builtin_fmaf(-sa, q, sw.z * cm);
+            return v3{sel ? first : sp, sel ? sp : first, lz};                // :413
+        }
+        const v3 t1{sel ? sw.z : 0.0f, sel ? 0.0f : -sw.z, sel ? -q : q};
+        const v3 t2 = cross(sw, t1);
         return (t1 * (cphi * g) + t2 * (sphi * g)) + sw * cos_a;              // :413
     }
     v3 su = tangent_u<Fast>(sw);

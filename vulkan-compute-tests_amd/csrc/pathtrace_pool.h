@@ -73,6 +73,8 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
         const uint32_t emits = (o[4] != 0.0f || o[5] != 0.0f || o[6] != 0.0f) ? 256u : 0u;
         r[7] = dm::as_float((uint32_t)(int)__builtin_floorf(o[11] + 0.5f) | emits);
         r[8] = o[4]; r[9] = o[5]; r[10] = o[6]; r[11] = Fast ? p : dm::rcp_short(p);
+        // fast math: the colour already divided by p (:392 and :397 as ONE multiplication past depth 5), with the same integer bits
+        if constexpr (Fast) { r[12] = o[8] * r[3]; r[13] = o[9] * r[3]; r[14] = o[10] * r[3]; r[15] = r[7]; }
     }
     __syncthreads();
     // fast math: the sphere tests of a bounce (three of the shadow ray, three of the next ray, all from the hit point x) read
@@ -144,8 +146,11 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
     const unsigned long long max_iters = (unsigned long long)n_batches * S * (a.max_depth + 2ull) + 64ull;
     for (unsigned long long it = 0; it < max_iters; it++) {
         // ---- lanes whose path ended take their pixel's next camera rays
+        // (MC_REGION: diagnostic build only — make stats, tools/pool_region_stats.py — executions and active lanes per block)
+        MC_REGION(0);    // an iteration
         const unsigned long long deadm = __ballot(!alive);
         if (deadm != 0ull) {
+            MC_REGION(1);    // refill bookkeeping
             const Lane me = my_lane(false);
             // the dead lanes of my pixel: S bits of the ballot starting at my pixel's first lane
             const uint32_t gbits = (uint32_t)(deadm >> (me.lane - me.sub)) & (S == 32 ? ~0u : ((1u << (S & 31)) - 1u));
@@ -173,6 +178,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
             }
             // one more batch when a pixel wants more rays than it has — and every pixel's ring has room for S more
             if (want) {
+                MC_REGION(2);    // a batch of camera rays
                 const Lane g = my_lane(MC_PT_POOL_KEEP_VALID ? false : true);
                 const uint32_t samp = a.sample_begin + batch * (uint32_t)S + g.sub;
                 const v3 crd = camera_ray<Fast>(a, gx, gy, samp);
@@ -183,7 +189,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                     oc0[i] = v3{a.cam_oc[i][0], a.cam_oc[i][1], a.cam_oc[i][2]};
                     occ0[i] = kOccR2 ? a.cam_occ[i] - hot.r2[i] : a.cam_occ[i];
                 }
-                int cid = intersect_slab<Fast, Fast, kOccR2>(hot, a.lc, crd, ct, false, occ0, oc0);
+                int cid = intersect_slab<Fast, Fast, kOccR2, 22>(hot, a.lc, crd, ct, false, occ0, oc0);
                 // nothing to trace: a pixel outside the tile, a sample beyond the range; a camera ray that misses everything (:369)
                 // gathers nothing either
                 if (!((MC_PT_POOL_KEEP_VALID ? pixel_valid : g.valid) && samp < a.sample_end)) cid = -1;
@@ -200,6 +206,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
             }
             const uint32_t rank = (uint32_t)__builtin_popcount(gbits & ((1u << me.sub) - 1u));   // dead lanes of my pixel below me
             if (!alive && rank < avail) {
+                MC_REGION(3);    // lanes taking a stash entry
                 const float4* q = reinterpret_cast<const float4*>(gstash + ((ghead + rank) & (Ring - 1u)) * kPoolEntryFloats);
                 const float4 q0 = q[0], q1 = q[1];
                 rd = v3{q0.x, q0.y, q0.z}; t = q0.w;
@@ -219,6 +226,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
         // (structured ifs, no break / continue: every extra exit edge of this block cost a dozen register copies at its merge)
         if (alive) {
             {
+                MC_REGION(4);    // a bounce: prologue
                 v3 x = ro + rd * t;                                               // :374
                 v3 xoc[3];                                                        // c_i - x (:317 at the next depth, :408 now)
 #pragma unroll
@@ -227,13 +235,17 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
 #pragma unroll
                 for (int i = 0; i < 3; i++) { xcc[i] = occ[i]; if constexpr (kOccR2) occ[i] = occ[i] - hot.r2[i]; }
                 const float4* obj = reinterpret_cast<const float4*>(lds_obj + kPoolRecordStride * (uint32_t)id);   // per-lane fetch
-                const float4 o0 = obj[0], o1 = obj[1];
+                // (fast: past depth 5 the colour row is the one already divided by the roulette probability)
+                const float4 o0 = obj[0], o1 = obj[(Fast && MC_PT_EXP_COLP && key > krr) ? 3 : 1];
                 const bool is_sphere = id >= 6;
                 v3 geo{o0.x, o0.y, o0.z};
                 v3 col{o1.x, o1.y, o1.z};
                 const uint32_t mbits = dm::as_uint(o1.w);
                 const int mat = (int)(mbits & 255u);                              // :378/:384
                 const float p = o0.w;                                             // :394 (fast: its reciprocal)
+#ifdef MC_PT_REGION_STATS
+                if (is_sphere) MC_REGION(5);    // sphere normal
+#endif
                 v3 n = is_sphere ? normalize<Fast>(x - geo) : geo;                // :381/:387
                 const float dot_n_rd = dot(n, rd);
                 v3 nl;                                                            // :390 nl = dot(n, rd) < 0 ? n : -n
@@ -245,17 +257,19 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                 }
                 v3& rad = Fast ? acc : accrad;                                    // where gathered radiance goes (see the header)
                 if (__ballot(mbits >= 256u) != 0ull) {                            // :391 (non-emitters add a zero: box_ok)
+                    MC_REGION(12);   // emission of a hit
                     const float4 o2 = obj[2];
                     rad = rad + (accmat * v3{o2.x, o2.y, o2.z}) * emissive;
                 }
                 accmat = accmat * col;                                            // :392
                 const v3 rnd{rx, ry, 0.0f};                                       // :393 (drawn at the end of the previous bounce)
-                if constexpr (Fast) accmat = accmat * (key > krr ? p : 1.0f);     // :395, :397 (:396 was decided there too)
+                if constexpr (Fast) { if (!MC_PT_EXP_COLP) accmat = accmat * (key > krr ? p : 1.0f); }   // :395, :397 (:396 was decided there too)
                 else if (key > krr) accmat = divs_recip<Fast>(accmat, p, obj[2].w);
                 bool go = true;
                 {
                 ro = x;                                                           // :429, :434, :447
                 if (mat == 1) {                                                   // :400 diffuse
+                    MC_REGION(13);   // diffuse: light sample + shadow test
                     v3 accmat_over_pi{0.0f, 0.0f, 0.0f};                          // strict: :422's accmat / pi, once per bounce
                     if constexpr (!Fast) accmat_over_pi = divs_recip<Fast>(accmat, kPi, kInvPi);
 #pragma unroll
@@ -269,6 +283,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                         if constexpr (Fast) lit = shadow_visible_disjoint<kOccR2>(hot, l, i, xoc, occ);            // (the host selects this kernel for disjoint spheres)
                         else lit = shadow_reaches_sphere<Fast>(hot, x, l, i, xoc[i], occ);
                         if (lit) {
+                            MC_REGION(8);    // light contribution
                             if constexpr (Fast) {
                                 const float scale = __builtin_fmaxf(dot(l, nl), 0.0f) * (2.0f - (cos_a_max + cos_a_max));   // :421-:422
                                 rad = rad + (accmat * le) * scale;
@@ -279,10 +294,11 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                         }
                     }
                     // :426-:428 (uniform: no lane of the wave bounces off a diffuse SPHERE — the light — in almost every iteration)
-                    if (__ballot(is_sphere) == 0ull) rd = cosine_bounce_wall<Fast>(id, rnd);
-                    else rd = cosine_bounce<Fast, true>(nl, rnd);
+                    if (__ballot(is_sphere) == 0ull) { MC_REGION(9); rd = cosine_bounce_wall<Fast>(id, rnd); }
+                    else { MC_REGION(10); rd = cosine_bounce<Fast, true>(nl, rnd); }
                     emissive = 0.0f;                                              // :429
                 } else {                                                          // :432 mirror, :437 glass (box_ok: 2 or 3)
+                    MC_REGION(11);   // mirror / glass
                     if constexpr (Fast) rd = specular_bounce_fast(mat, rd, n, dot_n_rd, rnd.x, accmat);
                     else rd = specular_bounce_general<false, true>(mat, rd, n, nl, dot_n_rd, rnd.x, accmat);
                     emissive = 1.0f;                                              // :447
@@ -290,13 +306,15 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                 key++;
                 go = key != kend;                                                 // :367 depth limit
                 if (go) {
-                    id = intersect_slab<Fast, Fast, kOccR2>(hot, ro, rd, t, false, occ, xoc);
+                    MC_REGION(14);   // intersection of the next depth
+                    id = intersect_slab<Fast, Fast, kOccR2, 16>(hot, ro, rd, t, false, occ, xoc);
                     go = id >= 0;                                                 // :369
                 }
                 if (go) {                                                         // the next bounce's random numbers and roulette
                     const v3 rn = rand01(gx, gy, key);                            // :393 (key = samp * maxDepth + depth)
                     rx = rn.x; ry = rn.y;
                     if (key > krr) {                                              // :395 depth > 5
+                        MC_REGION(15);   // roulette
                         const float4* nobj = reinterpret_cast<const float4*>(lds_obj + kPoolRecordStride * (uint32_t)id);
                         go = !(rn.z >= nobj[Fast ? 2 : 0].w);                     // :396
                         // a path the roulette ends has still gathered the emission of this hit (:391 precedes :396)
