@@ -38,6 +38,9 @@
 #ifndef MC_PT_POOL_KEEP_VALID   // the pixel's validity kept across the loop (a lane mask) instead of re-derived per batch
 #define MC_PT_POOL_KEEP_VALID 1
 #endif
+#ifndef MC_PT_POOL_LANE_REGS   // the refill's lane / sub kept in registers (two instructions an iteration less; both kernels have the room)
+#define MC_PT_POOL_LANE_REGS 1
+#endif
 #ifndef MC_PT_POOL_HOT_VGPR
 #define MC_PT_POOL_HOT_VGPR false
 #endif
@@ -89,7 +92,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
     struct Lane { uint32_t lane, pix, sub, ty; bool valid; };
     auto my_lane = [&](bool with_row) {
         uint32_t tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
+        if (!(MC_PT_POOL_LANE_REGS && !with_row)) asm volatile("" : "+v"(tid));   // (LANE_REGS: the refill's lane, sub stay in registers)
         Lane q;
         q.lane = tid & 63u; q.pix = q.lane / (uint32_t)S; q.sub = q.lane % (uint32_t)S;
         const uint32_t wave = tid >> 6;
