@@ -184,7 +184,9 @@ int mc_pathtrace_render_rgba8(mc_context* ctx, const mc_pathtrace_params* p, con
  * (the reference scene, pathtracerApp.h:14-39): the specialised slab kernels run; bit 1 (MC_PT_SCENE_LIGHTS_INSIDE) —
  * additionally the planes close a box, the camera (pathTracer.comp:352) and every emissive sphere lie inside it with a
  * margin: shadow rays (pathTracer.comp:420) skip the plane tests.  Both specialisations are bit-exact;
- * every other scene takes the generic kernel. */
+ * every other scene takes the generic kernel.  Bit 2 (MC_PT_SCENE_SPHERES_DISJOINT) — slab scenes: the three spheres are pairwise
+ * disjoint with a margin; only then does MC_PT_MATH_FAST take the sample-pool kernel, which orders the spheres a shadow ray meets by
+ * the projections of their centres (strict math does not depend on it). */
 #define MC_PT_SCENE_SLAB 1u
 #define MC_PT_SCENE_LIGHTS_INSIDE 2u
 #define MC_PT_SCENE_SPHERES_DISJOINT 4u   /* slab scenes: the three spheres are pairwise disjoint (the fast sample-pool kernel's premise) */

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Randomised sanity campaign for the FAST (toleranced) path tracer kernels on the GPU box — the counterpart of tools/fuzz_parity.py,
+which holds the strict kernels to bit-identity.  Fast math has no bit-exact reference, so every case is held to what a shortcut
+gone wrong would break: the output is finite (a NaN ray must gather nothing, csrc/pathtrace_kernel.h: intersect_slab<Closed>), and
+against the oracle evaluated with libm on the same sample keys only a few pixels may differ by more than a forked sample can move
+them, with no drift of the mean.  Scenes: random closed boxes with the camera and the lights inside — what the host selects the
+sample-pool kernel (disjoint spheres) or the closed-box round-synchronous kernel (overlapping spheres, forced widths) for — with any
+materials on the spheres, mirror walls, lights as any sphere, radii from specks to spheres that fill the room.
+
+    python tools/fuzz_fast.py [--seconds 300] [--seed 1]
+"""
+import argparse
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import __graft_entry__ as entry  # noqa: E402
+
+
+def scene(rng, O):
+    planes = O.DEFAULT_PLANES.copy().reshape(6, 12)
+    spheres = O.DEFAULT_SPHERES.copy().reshape(3, 12)
+    planes[:, 3] *= rng.uniform(0.85, 1.25, 6).astype(np.float32)
+    planes[:, 8:11] = rng.uniform(0.05, 0.999, (6, 3)).astype(np.float32)
+    if rng.random() < 0.4:
+        planes[rng.integers(6), 11] = 2.0                       # a mirror wall (a wall of glass leaves the closed-box class)
+    lo = np.array([-planes[0, 3], -planes[3, 3], -planes[4, 3]]) + 0.3
+    hi = np.array([planes[1, 3], planes[2, 3], min(planes[5, 3], 3.0)]) - 0.3
+    for i in range(3):
+        spheres[i, 3] = np.float32(rng.choice([rng.uniform(0.05, 0.3), rng.uniform(0.3, 1.0), rng.uniform(1.0, 1.6)], p=[0.3, 0.6, 0.1]))
+        spheres[i, 0:3] = rng.uniform(lo, hi).astype(np.float32)
+        spheres[i, 8:11] = rng.uniform(0.0, 0.999, 3).astype(np.float32)
+        spheres[i, 11] = float(rng.choice([1, 2, 3]))
+        spheres[i, 4:7] = 0
+    for i in rng.choice(3, int(rng.integers(1, 3)), replace=False):   # one or two lights, small, well inside the room
+        spheres[i, 4:7] = rng.uniform(5, 120, 3).astype(np.float32)
+        spheres[i, 8:11] = 0
+        spheres[i, 11] = 1.0
+        spheres[i, 3] = np.float32(rng.uniform(0.05, 0.4))
+        spheres[i, 0:3] = rng.uniform(lo + 0.4, hi - 0.4).astype(np.float32)
+    return planes, spheres
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300.0)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    B, O = entry.load_package().bindings, entry.load_oracle()
+    ctx = B.Context(0)
+    rng = np.random.default_rng(args.seed)
+    n = {"cases": 0, "closed_box": 0, "disjoint": 0}
+    worst = {"frac_far": 0.0, "mean": 0.0}
+    bad = []
+    t0 = last = time.time()
+    while time.time() - t0 < args.seconds:
+        planes, spheres = scene(rng, O)
+        cls = B.pathtrace_scene_class(planes, spheres)
+        W, H = int(rng.integers(8, 40)), int(rng.integers(8, 28))
+        spp = int(rng.choice([16, 24, 33, 64, 100]))
+        depth = int(rng.choice([12, 12, 5, 8]))
+        flags = int(rng.choice([0, 0, 0, B.PT_NO_POOL_KERNEL, B.pt_force_s(16), B.pt_force_s(1)]))
+        out = ctx.pathtrace(B.pathtrace_params(W, H, spp, max_depth=depth, math_mode=B.PT_MATH_FAST, flags=flags), planes=planes, spheres=spheres)
+        ref = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_LIBM, max_depth=depth)
+        n["cases"] += 1
+        n["closed_box"] += int(cls & 3 == 3)
+        n["disjoint"] += int(cls & 4 == 4)
+        d = out[..., :3].astype(np.float64) - ref[..., :3].astype(np.float64)
+        l2 = np.sqrt((d ** 2).sum(-1))
+        # A forked sample (a near-tie decided the other way) moves ONE pixel — usually by a few of its 255 / spp weights, up to
+        # saturation when it reaches a light through mirrors (emission ~100 on one of spp samples).  So: few pixels "far" (more than
+        # three weights), the typical pixel essentially equal, and the mean within what two saturated pixels could do.
+        far = float((l2 > 3.0 * 255.0 / spp).mean())
+        ok = (bool(np.isfinite(out).all()) and far <= 0.03 and float(np.median(l2)) <= 0.05
+              and abs(d.mean()) <= 0.05 + 2.0 * 255.0 / (W * H))
+        worst["frac_far"] = max(worst["frac_far"], far)
+        worst["mean"] = max(worst["mean"], abs(float(d.mean()))) if np.isfinite(d).all() else float("nan")
+        if not ok and len(bad) < 5:
+            bad.append(f"class={cls} W={W} H={H} spp={spp} depth={depth} flags={flags} finite={bool(np.isfinite(out).all())} far={far:.4f} "
+                       f"mean={d.mean():+.4f}\nplanes={planes.tolist()}\nspheres={spheres.tolist()}")
+            print("SUSPECT", bad[-1], flush=True)
+        if time.time() - last > 30:
+            last = time.time()
+            print(f"[{last - t0:5.0f} s] {n} worst {worst} suspects {len(bad)}", flush=True)
+    print(f"done: {n}, worst {worst}, suspects {len(bad)}")
+    ctx.close()
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
