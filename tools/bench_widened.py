@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Throughput of the rows SURVEY §8(f) widens into (2: the extended-precision sphere branches on the sphere-walled scene, 3: progressive
+sample ranges, 4: general scenes through the LDS-resident generic kernel), measured the way bench.py measures the headline: outputs
+resident in HBM, kernels on a torch stream, HIP events around a batch of launches, the CPU oracle on a bounded sample beside it where it
+takes seconds.  One JSON line per case (profiles/r03_bench_widened.jsonl).  Every case renders 900 x 600 like K2 (spp stated per case).
+
+    python tools/bench_widened.py [--reps 5]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as entry  # noqa: E402
+
+
+def room(rng, n_spheres, n_lights):
+    """The reference's six walls given in an order the slab analysis does not accept (so the GENERIC kernel runs) + random spheres."""
+    O = entry.load_oracle()
+    planes = O.DEFAULT_PLANES.copy().reshape(6, 12)[[2, 3, 0, 1, 4, 5]]
+    spheres = np.zeros((n_spheres, 12), np.float32)
+    spheres[:, 0] = rng.uniform(-2.2, 2.2, n_spheres); spheres[:, 1] = rng.uniform(-1.8, 1.2, n_spheres)
+    spheres[:, 2] = rng.uniform(-2.4, 2.5, n_spheres); spheres[:, 3] = rng.uniform(0.05, 0.35, n_spheres)
+    spheres[:, 8:11] = rng.uniform(0.2, 0.95, (n_spheres, 3)); spheres[:, 11] = rng.choice([1, 1, 1, 2, 3], n_spheres)
+    lights = rng.choice(n_spheres, n_lights, replace=False)
+    spheres[lights, 4:7] = rng.uniform(20, 80, (n_lights, 3)); spheres[lights, 8:11] = 0; spheres[lights, 11] = 1
+    spheres[lights, 1] = rng.uniform(1.2, 1.7, n_lights); spheres[lights, 3] = 0.15
+    return planes.astype(np.float32), spheres
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=5)
+    a = ap.parse_args()
+    B, O = entry.load_package().bindings, entry.load_oracle()
+    ctx = B.Context(0)
+    st = torch.cuda.Stream()
+    torch.cuda.set_stream(st)
+    s = st.cuda_stream
+    W, H = 900, 600
+    buf = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+
+    def timed(launches, reps=a.reps):
+        """launches(): enqueue one whole render; returns the best mean ms over 3 batches of `reps`."""
+        launches(); torch.cuda.synchronize()
+        best = 1e30
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                launches()
+            e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / reps)
+        return best
+
+    def cpu(spp_sample, rows, **kw):
+        t0 = time.time()
+        O.pathtrace(W, H, kw.pop("spp"), sample_begin=0, sample_end=spp_sample, row_begin=0, row_end=rows, **kw)
+        dt = time.time() - t0
+        return W * rows * spp_sample / dt, dt
+
+    def emit(row, name, spp, ms, note, cpu_rate=None, cpu_note=None):
+        rec = {"row": row, "case": name, "image": [W, H], "spp": spp, "ms_per_render": round(ms, 3), "samples_per_s": W * H * spp / (ms * 1e-3),
+               "note": note}
+        if cpu_rate:
+            rec["cpu_oracle_samples_per_s"] = cpu_rate
+            rec["cpu_note"] = cpu_note
+        print(json.dumps(rec), flush=True)
+
+    # ---- (f)2: the sphere-walled scene of TEST_PRECISION_WITH_LARGE_SPHERE_WALLS through the extended-precision sphere tests
+    LP, LS = O.LARGE_SPHERE_PLANES, O.LARGE_SPHERE_SPHERES
+    spp = 100
+    for prec, pname in ((B.PT_PREC_F32, "fp32 (the reference's default build)"), (B.PT_PREC_FP64, "native fp64 (:132-143)"),
+                        (B.PT_PREC_DS, "DS_f32_f32 (:144-213)"), (B.PT_PREC_DF64, "DF64_F32_F32 (:214-256)")):
+        for mode, mname in ((B.PT_MATH_STRICT, "strict"), (B.PT_MATH_FAST, "fast")):
+            p = B.pathtrace_params(W, H, spp, math_mode=mode, flags=B.pt_precision(prec))
+            ms = timed(lambda: ctx.pathtrace_device(p, buf.data_ptr(), planes=LP, spheres=LS, stream=s))
+            c = None
+            if mode == B.PT_MATH_STRICT:
+                c = cpu(2, 64, spp=spp, planes=LP, spheres=LS, math_mode=O.MATH_MC, precision=prec)
+            emit("f2", f"sphere-walled scene, sphere test {pname}, {mname}", spp, ms,
+                 "1 plane + 9 spheres (six of radius 1e5): generic kernel with the run-time precision switch",
+                 c[0] if c else None, f"oracle on the host cores, 2 samples x 64 rows ({c[1]:.1f} s)" if c else None)
+    # ---- (f)3: progressive sample ranges (the samps.x protocol), K2 scene, strict
+    spp = 500
+    whole = B.pathtrace_params(W, H, spp)
+    ms_whole = timed(lambda: ctx.pathtrace_device(whole, buf.data_ptr(), stream=s))
+    emit("f3", "K2 strict, one launch", spp, ms_whole, "strict sample-pool kernel")
+    for parts in (5, 25):
+        cuts = [round(i * spp / parts) for i in range(parts + 1)]
+        ps = [B.pathtrace_params(W, H, spp, sample_begin=b, sample_end=e) for b, e in zip(cuts[:-1], cuts[1:])]
+
+        def run():
+            for q in ps:
+                ctx.pathtrace_device(q, buf.data_ptr(), stream=s)
+        ms = timed(run)
+        emit("f3", f"K2 strict in {parts} ranges of {spp // parts} samples (accumulator continued in the buffer)", spp, ms,
+             f"strict sample-pool kernel per range; {ms / ms_whole:.3f} x the one-launch time")
+    # ---- (f)4: general scenes through the generic (LDS-resident scene) kernel
+    rng = np.random.default_rng(5)
+    spp = 100
+    DP, DS = O.DEFAULT_PLANES.copy().reshape(6, 12), O.DEFAULT_SPHERES.copy().reshape(3, 12)
+    for name, planes, spheres in (("the default scene with its planes permuted (generic kernel on K2's geometry)", DP[[2, 3, 0, 1, 4, 5]], DS),
+                                  ("6 planes + 64 spheres", *room(rng, 64, 3)), ("6 planes + 512 spheres", *room(rng, 512, 5)),
+                                  ("6 planes + 1500 spheres", *room(rng, 1500, 8))):
+        assert B.pathtrace_scene_class(planes, spheres) == 0
+        for mode, mname in ((B.PT_MATH_STRICT, "strict"), (B.PT_MATH_FAST, "fast")):
+            p = B.pathtrace_params(W, H, spp, math_mode=mode)
+            ms = timed(lambda: ctx.pathtrace_device(p, buf.data_ptr(), planes=planes, spheres=spheres, stream=s), reps=max(1, a.reps // 2))
+            c = None
+            if mode == B.PT_MATH_STRICT:
+                rows = 64 if len(spheres) <= 64 else 8
+                c = cpu(2, rows, spp=spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC)
+            emit("f4", f"{name}, {mname}", spp, ms, f"{len(planes)} planes + {len(spheres)} spheres, records staged in LDS by every block",
+                 c[0] if c else None, f"oracle on the host cores, 2 samples x {rows} rows ({c[1]:.1f} s)" if c else None)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
