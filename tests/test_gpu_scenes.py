@@ -68,11 +68,19 @@ def test_scene_beyond_48k_of_lds(ctx, B, O):
 
 
 def test_scene_too_large_is_rejected(ctx, B):
+    """Beyond the LDS-resident store (about 3000 objects) only the fp32 kernels run (from memory, below); a forced LDS copy, an
+    extended-precision branch and more than 2^20 objects are MC_ERR_UNSUPPORTED."""
     planes = np.zeros((4000, 12), np.float32)
     planes[:, 0] = 1.0
+    for flags in (B.PT_SCENE_IN_LDS, B.pt_precision(B.PT_PREC_FP64)):
+        with pytest.raises(B.McError) as e:
+            ctx.pathtrace(B.pathtrace_params(8, 8, 1, flags=flags), planes=planes, spheres=np.zeros((1, 12), np.float32))
+        assert e.value.status == 5     # MC_ERR_UNSUPPORTED
+    huge = np.zeros(((1 << 20) + 1, 12), np.float32)
+    huge[:, 0] = 1.0
     with pytest.raises(B.McError) as e:
-        ctx.pathtrace(B.pathtrace_params(8, 8, 1), planes=planes, spheres=np.zeros((1, 12), np.float32))
-    assert e.value.status == 5     # MC_ERR_UNSUPPORTED
+        ctx.pathtrace(B.pathtrace_params(8, 8, 1), planes=huge, spheres=np.zeros((1, 12), np.float32))
+    assert e.value.status == 5
 
 
 def test_scene_change_between_launches(ctx, B, O):
@@ -172,3 +180,34 @@ def test_fast_mode_on_a_scene_with_non_unit_plane_normals(ctx, B, O):
         rmse, p999 = np.sqrt((d ** 2).mean()), np.percentile(np.sqrt((d ** 2).sum(-1)), 99.9)
         print(f"non-unit normals, fast generic flags={flags}: rmse {rmse:.4f} p99.9 {p999:.3f}")
         assert rmse <= 0.75 and p999 <= 5.0 and abs(d.mean()) < 0.25
+
+
+@pytest.mark.parametrize("n_planes,n_spheres,n_lights", [(6, 40, 3), (1, 1, 1), (12, 700, 4)])
+def test_generic_scene_read_from_memory_is_bit_identical(ctx, B, O, n_planes, n_spheres, n_lights):
+    """Large generic scenes are not staged into LDS but read where they lie (csrc/pathtrace.hip: kSceneLdsAutoBytes; scalar loads in
+    the intersection loops, a vector load for the material fetch).  Forced either way — MC_PT_SCENE_IN_LDS, MC_PT_SCENE_IN_MEMORY —
+    and left to the host, strict renders are bit-identical to the oracle; fast renders of the two paths are bit-identical to each
+    other (the same instruction sequence on the same values)."""
+    rng = np.random.default_rng(n_spheres)
+    planes, spheres = random_scene(rng, n_planes, n_spheres, n_lights)
+    W, H, spp = (24, 16, 6) if n_spheres > 100 else (48, 32, 9)
+    ref = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC)
+    for flags in (0, B.PT_SCENE_IN_LDS, B.PT_SCENE_IN_MEMORY, B.PT_SCENE_IN_MEMORY | B.pt_force_s(1), B.PT_SCENE_IN_MEMORY | B.pt_force_s(16)):
+        out = ctx.pathtrace(B.pathtrace_params(W, H, spp, flags=flags), planes=planes, spheres=spheres)
+        assert np.array_equal(bits(out), bits(ref)), flags
+    f_lds = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, flags=B.PT_SCENE_IN_LDS), planes=planes, spheres=spheres)
+    f_mem = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, flags=B.PT_SCENE_IN_MEMORY), planes=planes, spheres=spheres)
+    assert np.array_equal(bits(f_lds), bits(f_mem))
+
+
+def test_scene_beyond_the_lds_store_renders_from_memory(ctx, B, O):
+    """4000 spheres (192 KB of records: more than a CU's LDS) were MC_ERR_UNSUPPORTED before round 3's memory path; now the fp32
+    kernels take them (bit-identical to the oracle on a few pixels), the extended-precision branches and a forced LDS copy still refuse."""
+    rng = np.random.default_rng(9)
+    planes, spheres = random_scene(rng, 6, 4000, 3)
+    W, H, spp = 8, 6, 2
+    out = ctx.pathtrace(B.pathtrace_params(W, H, spp), planes=planes, spheres=spheres)
+    assert np.array_equal(bits(out), bits(O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC)))
+    for flags in (B.PT_SCENE_IN_LDS, B.pt_precision(B.PT_PREC_DS)):
+        with pytest.raises(B.McError):
+            ctx.pathtrace(B.pathtrace_params(W, H, spp, flags=flags), planes=planes, spheres=spheres)

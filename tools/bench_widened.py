@@ -108,18 +108,23 @@ def main():
     spp = 100
     DP, DS = O.DEFAULT_PLANES.copy().reshape(6, 12), O.DEFAULT_SPHERES.copy().reshape(3, 12)
     for name, planes, spheres in (("the default scene with its planes permuted (generic kernel on K2's geometry)", DP[[2, 3, 0, 1, 4, 5]], DS),
-                                  ("6 planes + 64 spheres", *room(rng, 64, 3)), ("6 planes + 512 spheres", *room(rng, 512, 5)),
-                                  ("6 planes + 1500 spheres", *room(rng, 1500, 8))):
+                                  ("6 planes + 64 spheres", *room(rng, 64, 3)), ("6 planes + 256 spheres", *room(rng, 256, 4)),
+                                  ("6 planes + 512 spheres", *room(rng, 512, 5)), ("6 planes + 1500 spheres", *room(rng, 1500, 8)),
+                                  ("6 planes + 6000 spheres (beyond the LDS store)", *room(rng, 6000, 8))):
         assert B.pathtrace_scene_class(planes, spheres) == 0
         for mode, mname in ((B.PT_MATH_STRICT, "strict"), (B.PT_MATH_FAST, "fast")):
-            p = B.pathtrace_params(W, H, spp, math_mode=mode)
-            ms = timed(lambda: ctx.pathtrace_device(p, buf.data_ptr(), planes=planes, spheres=spheres, stream=s), reps=max(1, a.reps // 2))
-            c = None
-            if mode == B.PT_MATH_STRICT:
-                rows = 64 if len(spheres) <= 64 else 8
-                c = cpu(2, rows, spp=spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC)
-            emit("f4", f"{name}, {mname}", spp, ms, f"{len(planes)} planes + {len(spheres)} spheres, records staged in LDS by every block",
-                 c[0] if c else None, f"oracle on the host cores, 2 samples x {rows} rows ({c[1]:.1f} s)" if c else None)
+            for where, flag in (("LDS", B.PT_SCENE_IN_LDS), ("memory", B.PT_SCENE_IN_MEMORY)):
+                if len(spheres) > 3000 and where == "LDS":
+                    continue
+                p = B.pathtrace_params(W, H, spp, math_mode=mode, flags=flag)
+                reps = 1 if len(spheres) > 1000 else max(1, a.reps // 2)
+                ms = timed(lambda: ctx.pathtrace_device(p, buf.data_ptr(), planes=planes, spheres=spheres, stream=s), reps=reps)
+                c = None
+                if mode == B.PT_MATH_STRICT and where == "memory":
+                    rows = 64 if len(spheres) <= 64 else (8 if len(spheres) <= 1500 else 2)
+                    c = cpu(2, rows, spp=spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC)
+                emit("f4", f"{name}, {mname}, records in {where}", spp, ms, f"{len(planes)} planes + {len(spheres)} spheres through the generic kernel",
+                     c[0] if c else None, f"oracle on the host cores, 2 samples x {rows} rows ({c[1]:.1f} s)" if c else None)
     ctx.close()
 
 

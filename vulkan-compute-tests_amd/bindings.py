@@ -23,6 +23,8 @@ PT_GENERIC_KERNEL = 1
 PT_KERNEL_REGROUP = 2   # diagnostic library only (lib/libmc_compute_regroup.so)
 PT_NO_BOX_KERNEL = 4    # fast math: the general slab kernel instead of the closed-box ones
 PT_NO_POOL_KERNEL = 8   # fast math: the round-synchronous closed-box kernel instead of the sample-pool kernel
+PT_SCENE_IN_LDS = 16    # generic scenes: records staged into LDS by every block (automatic for small scenes) ...
+PT_SCENE_IN_MEMORY = 32  # ... or read where they lie (automatic for large ones); same results
 PT_PREC_F32, PT_PREC_FP64, PT_PREC_DS, PT_PREC_DF64 = 0, 1, 2, 3
 DS_OPS = {"add": 0, "sub": 1, "mul": 2, "compare": 3, "sqrt": 4, "df64_add": 5, "df64_mult": 6, "df64_sqrt": 7, "twoprod": 8,
           "div": 9, "twodiff": 10, "df64_eqneq": 11, "mul_fma": 12}

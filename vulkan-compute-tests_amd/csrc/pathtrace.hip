@@ -135,8 +135,15 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
         return MC_ERR_INVALID_ARGUMENT;
     if (p->math_mode != MC_PT_MATH_STRICT && p->math_mode != MC_PT_MATH_FAST) return MC_ERR_INVALID_ARGUMENT;
     if (p->row_stride && (!p->row_block || p->row_block > p->row_stride)) return MC_ERR_INVALID_ARGUMENT;
-    if (((size_t)n_planes + n_spheres) * 48u + (size_t)n_spheres * 4u > pt::kMaxSceneLdsBytes) {
-        set_error_detail("scene exceeds the LDS-resident scene store (about 3000 objects)");
+    // A scene beyond the LDS-resident store (about 3000 objects) is read from memory — by the fp32 kernels; the extended-precision
+    // sphere branches exist for LDS-resident scenes only, as does the forced MC_PT_SCENE_IN_LDS.
+    const bool beyond_lds = ((size_t)n_planes + n_spheres) * 48u + (size_t)n_spheres * 4u > pt::kMaxSceneLdsBytes;
+    if (beyond_lds && ((((p->flags >> 16) & 0xffu) != 0u) || (p->flags & MC_PT_SCENE_IN_LDS))) {
+        set_error_detail("scene exceeds the LDS-resident scene store (about 3000 objects): fp32 sphere test from memory only");
+        return MC_ERR_UNSUPPORTED;
+    }
+    if (((size_t)n_planes + n_spheres) > (1u << 20)) {
+        set_error_detail("more than 2^20 objects");
         return MC_ERR_UNSUPPORTED;
     }
     PTArgs a;
@@ -191,8 +198,10 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
         a.scene.spheres_disjoint = spheres_disjoint(spheres) ? 1u : 0u;
         // closed-box fast kernel: no ray may ever leave the box (pathtrace_kernel.h, intersect_box)
         a.scene.box_ok = (a.scene.nee_skip_planes && a.scene.materials_known && !glass_wall && a.scene.emit_skip_ok) ? 1u : 0u;
-    } else {      // any other scene: device buffer [records | emissive sphere indices], staged into LDS by the kernel
-        std::vector<float> host((size_t)(n_planes + n_spheres) * 12 + n_spheres);
+    } else {      // any other scene: device buffer [records | emissive sphere indices | records with the derived slots], staged
+                  // into LDS by the kernel — or, for large scenes, read where they lie (the third part)
+        const size_t n_rec = (size_t)(n_planes + n_spheres) * 12;
+        std::vector<float> host(n_rec + n_spheres);
         if (n_planes) std::memcpy(host.data(), planes, sizeof(float) * 12 * n_planes);
         if (n_spheres) std::memcpy(host.data() + 12 * (size_t)n_planes, spheres, sizeof(float) * 12 * n_spheres);
         uint32_t* em = reinterpret_cast<uint32_t*>(host.data() + (size_t)(n_planes + n_spheres) * 12);
@@ -202,7 +211,15 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
             v3 e{sp[4], sp[5], sp[6]};
             if (h_dot(e, e) > 0.0f) em[n_em++] = i;                      // pathTracer.comp:407
         }
-        host.resize((size_t)(n_planes + n_spheres) * 12 + n_em);
+        host.resize(n_rec + n_em);
+        host.resize(n_rec + n_em + n_rec);   // the staged copy's derived slots (pathtrace_kernel.h, stage_records): the same fp32 operations
+        for (size_t k = 0; k < (size_t)(n_planes + n_spheres); k++) {
+            float* o = host.data() + n_rec + n_em + 12 * k;
+            std::memcpy(o, host.data() + 12 * k, 12 * sizeof(float));
+            const float m01 = (o[8] < o[9]) ? o[9] : o[8];        // dm::gmax
+            o[7] = (m01 < o[10]) ? o[10] : m01;
+            o[11] = floorf(o[11] + 0.5f);
+        }
         if (host != ctx->scene_host || !ctx->scene_buf.ptr) {            // upload only when the scene changed
             // Earlier launches of THIS context may still read the old copy: wait for the streams it has launched on
             // (never the whole device — other contexts and streams keep running), then upload in stream order.
@@ -215,7 +232,8 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
             ctx->scene_host = std::move(host);
         }
         a.scene.d_obj = (const float*)ctx->scene_buf.ptr;
-        a.scene.d_emissive = (const uint32_t*)((const float*)ctx->scene_buf.ptr + (size_t)(n_planes + n_spheres) * 12);
+        a.scene.d_emissive = (const uint32_t*)((const float*)ctx->scene_buf.ptr + n_rec);
+        a.scene.d_obj_derived = (const float*)ctx->scene_buf.ptr + n_rec + n_em;
         a.scene.n_emissive = n_em;
     }
     const uint32_t rows = tile_rows(p->row_begin, p->row_end, a.row_block, a.row_stride);
@@ -224,6 +242,15 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
     if (S != 1 && S != 4 && S != 16) return MC_ERR_INVALID_ARGUMENT;
     if (prec != 0 && S == 4) S = (p->sample_end - p->sample_begin) >= 16 ? 16 : 1;   // precision variants exist for S = 1, 16
     int variant = slab ? 1 : 0;
+    // Generic scenes (fp32 sphere test): the records are staged into LDS by every block while that leaves room for a full set of
+    // blocks per CU, else read from memory (MC_PT_SCENE_IN_LDS / MC_PT_SCENE_IN_MEMORY force one or the other; same results)
+    if (!slab && prec == 0) {
+        const size_t lds = ((size_t)(n_planes + n_spheres) * 12u + a.scene.n_emissive) * sizeof(float);
+        bool in_memory = lds > pt::kSceneLdsAutoBytes;
+        if (p->flags & MC_PT_SCENE_IN_LDS) in_memory = false;
+        if (p->flags & MC_PT_SCENE_IN_MEMORY) in_memory = true;
+        if (in_memory) variant = 5;
+    }
     if (slab && a.scene.box_ok && !(p->flags & MC_PT_NO_BOX_KERNEL)) {
         const bool fast = p->math_mode == MC_PT_MATH_FAST;
         if (fast) variant = 3;   // the closed-box round-synchronous kernels (scene facts at compile time)

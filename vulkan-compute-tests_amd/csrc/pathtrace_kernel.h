@@ -75,6 +75,9 @@ struct SceneArgs {
     // indices live in a device buffer and are staged into dynamic LDS by every block — obj[]/r2[]/emissive_mask
     // above are then unused.  Capacity is bounded by the 160 KB of LDS per CU, not by the kernel-argument segment.
     const float* d_obj;
+    // the same records with the staged copy's derived slots ([7] = max colour component, [11] = floor(m + 0.5), stage_records)
+    // already in place: read directly from memory by the kernels that leave the scene there (NP = NS = -2; large scenes)
+    const float* d_obj_derived;
     const uint32_t* d_emissive;
     uint32_t n_emissive;
     // Fast math, slab scenes: non-zero when the three spheres are pairwise disjoint with a margin (pathtrace.hip): the order of
@@ -974,7 +977,12 @@ __global__ void __launch_bounds__(256, Fast ? 6 : 5) pathtrace_kernel(PTArgs a) 
     float* lds_obj = lds_dyn;
     const uint32_t count = (a.scene.n_planes + a.scene.n_spheres) * 12u;
     uint32_t* lds_emissive = reinterpret_cast<uint32_t*>(lds_dyn + count);
-    if (NP < 0) {   // generic: stage from the device buffer (its intersection loops read this copy too: slot 3 stays)
+    if (NP == -2) {   // generic, scene left in memory: the intersection loops read the records with wave-uniform indices
+                      // (scalar loads through the constant cache), the per-lane material fetch is a vector load; no LDS at all,
+                      // so a scene of thousands of objects does not cost occupancy (one 144 KB block per CU otherwise)
+        lds_obj = const_cast<float*>(a.scene.d_obj_derived);
+        lds_emissive = const_cast<uint32_t*>(a.scene.d_emissive);
+    } else if (NP < 0) {   // generic: stage from the device buffer (its intersection loops read this copy too: slot 3 stays)
         for (uint32_t i = threadIdx.x; i < a.scene.n_emissive; i += blockDim.x) lds_emissive[i] = a.scene.d_emissive[i];
         stage_records(lds_obj, a.scene.d_obj, a.scene.n_planes + a.scene.n_spheres, false);
     } else {        // specialised: stage the kernel-argument copy for the per-lane material fetch
@@ -1079,11 +1087,15 @@ inline size_t scene_lds_bytes(const PTArgs& a) {
     return ((size_t)(a.scene.n_planes + a.scene.n_spheres) * 12u + a.scene.n_emissive) * sizeof(float);
 }
 constexpr size_t kMaxSceneLdsBytes = 144u * 1024u;   // of the 160 KB per CU: 3072 objects
+// Generic scenes larger than this are read from memory instead of being staged into LDS by every block (pathtrace.hip).  Measured
+// (tools/bench_widened.py, per object and ray): LDS 0.22 at 6 blocks per CU (512 spheres, 25 KB), 0.55 at 2 (1500 spheres, 72 KB);
+// memory 0.27-0.30 whatever the size — the LDS copy wins while four blocks fit a CU's 160 KB.
+constexpr size_t kSceneLdsAutoBytes = 36u * 1024u;
 
 template <bool Fast, int NP, int NS, bool Slab, int S, int Prec, bool Box = false>
 inline int launch_one(const PTArgs& a, uint32_t tile_rows, hipStream_t s) {
     dim3 grid((a.W + block_w<S>() - 1u) / block_w<S>(), (tile_rows + block_h<S>() - 1u) / block_h<S>());
-    size_t lds = scene_lds_bytes(a);
+    size_t lds = NP == -2 ? 0u : scene_lds_bytes(a);
 #ifdef MC_PT_DIAG_LDS_PAD   // diagnostic build only (make variants): pad the dynamic LDS to cap the resident waves per CU
     if (const char* e = std::getenv("MC_PT_LDS_PAD")) lds += (size_t)std::atoi(e);
 #endif
@@ -1115,6 +1127,10 @@ inline int launch_impl(const PTArgs& a, int variant, int S, int prec, uint32_t t
             if (S == 1) return launch_one<Fast, 6, 3, true, 1, 0>(a, tile_rows, s);
             if (S == 4) return launch_one<Fast, 6, 3, true, 4, 0>(a, tile_rows, s);
             if (S == 16) return launch_one<Fast, 6, 3, true, 16, 0>(a, tile_rows, s);
+        } else if (variant == 5) {   // generic, scene read from memory
+            if (S == 1) return launch_one<Fast, -2, -2, false, 1, 0>(a, tile_rows, s);
+            if (S == 4) return launch_one<Fast, -2, -2, false, 4, 0>(a, tile_rows, s);
+            if (S == 16) return launch_one<Fast, -2, -2, false, 16, 0>(a, tile_rows, s);
         } else {
             if (S == 1) return launch_one<Fast, -1, -1, false, 1, 0>(a, tile_rows, s);
             if (S == 4) return launch_one<Fast, -1, -1, false, 4, 0>(a, tile_rows, s);
