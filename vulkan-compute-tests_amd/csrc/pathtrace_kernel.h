@@ -358,10 +358,12 @@ struct HotSlab {
     float c[3][3], r2[3];        // sphere centres, radius^2 (the fp32 product of pathTracer.comp:318)
     float eps, tri_eps, inf;     // kEps, kTriEps, kInf
     // InVgpr = false leaves the values to the compiler (SGPR operands): for kernels without the register headroom.
-    template <bool InVgpr = true> __device__ __forceinline__ void load(const SceneArgs& sc) {
+    // WPosInVgpr: only W_pos in vector registers — the select `d_a > 0 ? W_pos : W_negm` then is ONE v_cndmask (SGPR, VGPR, vcc)
+    // instead of two v_mov and a v_cndmask (a VOP3 select reads its mask and one more scalar at most).
+    template <bool InVgpr = true, bool WPosInVgpr = false> __device__ __forceinline__ void load(const SceneArgs& sc) {
         auto put = [](float u) { return InVgpr ? to_vgpr(u) : u; };
 #pragma unroll
-        for (int a = 0; a < 3; a++) { W_pos[a] = put(sc.slab_w_pos[a]); W_negm[a] = put(-sc.slab_w_neg[a]); }
+        for (int a = 0; a < 3; a++) { W_pos[a] = (InVgpr || WPosInVgpr) ? to_vgpr(sc.slab_w_pos[a]) : sc.slab_w_pos[a]; W_negm[a] = put(-sc.slab_w_neg[a]); }
 #pragma unroll
         for (int i = 0; i < 3; i++) {
 #pragma unroll

@@ -41,6 +41,9 @@
 #ifndef MC_PT_POOL_LANE_REGS   // the refill's lane / sub kept in registers (two instructions an iteration less; both kernels have the room)
 #define MC_PT_POOL_LANE_REGS 1
 #endif
+#ifndef MC_PT_POOL_HOT_W
+#define MC_PT_POOL_HOT_W true
+#endif
 #ifndef MC_PT_POOL_HOT_VGPR
 #define MC_PT_POOL_HOT_VGPR false
 #endif
@@ -85,7 +88,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
     constexpr bool kOccR2 = Fast && MC_PT_EXP_OCR;
     constexpr uint32_t TW = WaveTile<S>::w, TH = WaveTile<S>::h, Ring = 2u * (uint32_t)S, RRing = kPoolResultBatches * (uint32_t)S;
     HotSlab hot;
-    hot.load<MC_PT_POOL_HOT_VGPR>(a.scene);   // (uniform operands: this kernel has no vector registers to spare for copies)
+    hot.load<MC_PT_POOL_HOT_VGPR, MC_PT_POOL_HOT_W>(a.scene);   // (uniform operands: this kernel has no vector registers to spare for copies)
     // A lane's pixel (pix = lane / S of the wave tile) and slot of a batch (sub = lane % S) never change.  What derives from them
     // and is needed only now and then — the stash base, the tile row, the validity — is derived afresh from an opaque copy of
     // the thread id where it is used, so that it does not occupy registers across the bounce loop (80 VGPRs = 6 waves per SIMD).
