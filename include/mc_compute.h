@@ -122,7 +122,8 @@ enum {
     MC_PT_NO_POOL_KERNEL = 1u << 3, /* fast math: never use the sample-pool kernel (csrc/pathtrace_pool.h); the round-        */
                                     /* synchronous closed-box kernel runs instead                                            */
     MC_PT_SCENE_IN_LDS = 1u << 4,   /* generic scenes: every block stages the object records into LDS (the automatic choice   */
-    MC_PT_SCENE_IN_MEMORY = 1u << 5 /* for small scenes) / the kernel reads them where they lie (large scenes); same results  */
+    MC_PT_SCENE_IN_MEMORY = 1u << 5 /* for small scenes) / the kernel reads them where they lie (large scenes); strict math:  */
+                                    /* bit-identical either way                                                             */
 };
 #define MC_PT_FORCE_S(s) ((uint32_t)(s) << 8) /* force the sample-parallel width: 1, 4 or 16 (0 = automatic) */
 /* Sphere-test precision branch of pathTracer.comp:132-256.  The reference compiles every variant OUT

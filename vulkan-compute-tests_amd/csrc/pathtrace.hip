@@ -212,9 +212,10 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
             if (h_dot(e, e) > 0.0f) em[n_em++] = i;                      // pathTracer.comp:407
         }
         host.resize(n_rec + n_em);
-        host.resize(n_rec + n_em + n_rec);   // the staged copy's derived slots (pathtrace_kernel.h, stage_records): the same fp32 operations
+        const size_t derived_at = n_rec + ((n_em + 3u) & ~(size_t)3u);   // 16-byte aligned like the records: the kernels read (centre, radius) as one float4
+        host.resize(derived_at + n_rec);   // the staged copy's derived slots (pathtrace_kernel.h, stage_records): the same fp32 operations
         for (size_t k = 0; k < (size_t)(n_planes + n_spheres); k++) {
-            float* o = host.data() + n_rec + n_em + 12 * k;
+            float* o = host.data() + derived_at + 12 * k;
             std::memcpy(o, host.data() + 12 * k, 12 * sizeof(float));
             const float m01 = (o[8] < o[9]) ? o[9] : o[8];        // dm::gmax
             o[7] = (m01 < o[10]) ? o[10] : m01;
@@ -233,7 +234,7 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
         }
         a.scene.d_obj = (const float*)ctx->scene_buf.ptr;
         a.scene.d_emissive = (const uint32_t*)((const float*)ctx->scene_buf.ptr + n_rec);
-        a.scene.d_obj_derived = (const float*)ctx->scene_buf.ptr + n_rec + n_em;
+        a.scene.d_obj_derived = (const float*)ctx->scene_buf.ptr + derived_at;
         a.scene.n_emissive = n_em;
     }
     const uint32_t rows = tile_rows(p->row_begin, p->row_end, a.row_block, a.row_stride);

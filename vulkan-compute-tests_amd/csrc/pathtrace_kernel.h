@@ -265,6 +265,9 @@ struct WaveTime {};
 #ifndef MC_PT_EXP_PID
 #define MC_PT_EXP_PID 1
 #endif
+#ifndef MC_PT_GENERIC_PREFETCH
+#define MC_PT_GENERIC_PREFETCH 1
+#endif
 #ifndef MC_PT_EXP_FRAME
 #define MC_PT_EXP_FRAME 1
 #endif
@@ -584,10 +587,25 @@ __device__ __forceinline__ int intersect(const SceneArgs& sc, const float* __res
             }
         }
     }
+    // Scenes read from memory (NP = -2): the next sphere's (centre, radius) is fetched — one scalar load — before the current one is
+    // tested, so its latency hides behind the ~15 instructions of a sphere test instead of stalling the wave at the top of every
+    // iteration: 5-11 % at 1500 spheres.  (Measured the other way for the LDS copy — 5-10 % SLOWER at 64 and 512 spheres: its
+    // broadcast reads are short enough already — so only here.)  Same values, same order.
+    constexpr bool Prefetch = NP == -2 && MC_PT_GENERIC_PREFETCH;
+    float4 nxt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (Prefetch && ns > 0) nxt = *reinterpret_cast<const float4*>(obj + 12 * np);
 #pragma unroll
     for (int i = 0; i < ns; i++) {
         const float* sp = obj + 12 * (np + i);
-        const float r2 = LdsScene ? sp[3] * sp[3] : sc.r2[i];   // the fp32 product of :318 either way
+        float4 cur;
+        if (Prefetch) {
+            cur = nxt;
+            const int j = (i + 1 < ns) ? i + 1 : i;
+            nxt = *reinterpret_cast<const float4*>(obj + 12 * (np + j));
+        } else {
+            cur = make_float4(sp[0], sp[1], sp[2], sp[3]);
+        }
+        const float r2 = LdsScene ? cur.w * cur.w : sc.r2[i];   // the fp32 product of :318 either way
         bool extended = false;
         if (Prec != 0) {
             extended = needs_precision(sp, o);
@@ -596,7 +614,7 @@ __device__ __forceinline__ int intersect(const SceneArgs& sc, const float* __res
                 if (sphere_extended<Fast, Prec>(sp, r2, o, d, dd) && dd < t) { t = dd; id = np + i; }   // :333
             }
         }
-        v3 oc = v3{sp[0], sp[1], sp[2]} - o;                                 // :317
+        v3 oc = v3{cur.x, cur.y, cur.z} - o;                                 // :317
         float b = dot(oc, d);                                                // :318
         float det = (b * b - dot(oc, oc)) + r2;
         if (!extended && !(det < 0.0f)) {                                    // :319
