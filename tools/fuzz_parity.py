@@ -96,7 +96,8 @@ def fuzz_pathtrace(rng, ctx, B, O):
         W, H, spp = int(rng.integers(1, 12)), int(rng.integers(1, 10)), int(rng.integers(20, 200))
     depth = int(rng.choice([12, 12, 12, 3, 7, 15]))
     # 0: the automatic choice (the strict sample-pool kernel for closed-box scenes, else the round-synchronous kernels)
-    flags = int(rng.choice([0, 0, 0, B.pt_force_s(1), B.pt_force_s(4), B.pt_force_s(16), B.PT_GENERIC_KERNEL, B.PT_NO_POOL_KERNEL]))
+    flags = int(rng.choice([0, 0, 0, B.pt_force_s(1), B.pt_force_s(4), B.pt_force_s(16), B.PT_GENERIC_KERNEL, B.PT_NO_POOL_KERNEL,
+                            B.PT_GENERIC_KERNEL | B.PT_SCENE_IN_MEMORY]))   # (the last: the generic kernel reading the scene from memory)
     cls = B.pathtrace_scene_class(planes, spheres)
     out = ctx.pathtrace(B.pathtrace_params(W, H, spp, max_depth=depth, flags=flags), planes=planes, spheres=spheres)
     ref = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC, max_depth=depth)
