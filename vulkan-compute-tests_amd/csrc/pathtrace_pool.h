@@ -1,4 +1,5 @@
-// The sample-pool path tracer kernel for gfx950 — fast math, closed-box scenes (SceneArgs::box_ok).  Included by pathtrace_fast.hip.
+// The sample-pool path tracer kernels for gfx950 — closed-box scenes (SceneArgs::box_ok); fast math (included by pathtrace_fast.hip)
+// and strict math (pathtrace_strict.hip).
 //
 // Why: the round-synchronous kernels (pathtrace_kernel.h) step all 64 lanes of a wave through the depths of ONE sample each;
 // Russian roulette (pathTracer.comp:395-397) thins the wave from depth 6 on and the round still costs its longest path, so the
@@ -23,11 +24,13 @@
 // order — the fold of the round-synchronous kernels, fed from LDS — once every sample of the batch has ended (oldest live sample
 // of the pixel by a 4-step butterfly, only when a new batch is wanted).  Same decisions, same operations, same order: exact.
 //
-// Parity (fast): each sample's arithmetic is exactly that of the fast closed-box round-synchronous kernel (the same inlined functions);
-// what differs is the ORDER in which a pixel's fp32 contributions are added — the reference adds accrad/spp sample by sample
-// (:451-:452), here every lane sums the contributions of the samples it happened to trace and the S partial sums are added at
-// the end — a reassociation, relative 1e-6 of the pixel value, far inside the fast-math tolerance and the reason
-// this kernel exists for MC_PT_MATH_FAST only.  It is deterministic: a wave's schedule depends on nothing outside the wave, and
+// Parity (fast): a sample follows the fast closed-box round-synchronous kernel's arithmetic (the same inlined functions) except for
+// the cheaper equivalent forms this kernel alone uses — the bounce off a wall as a signed permutation (the same values), shadow rays
+// decided by comparing squares and centre projections (disjoint spheres: the host's premise for selecting it), |c - x|^2 - r^2 and
+// colour / p formed once — DESIGN.md §3.3; beyond that what differs is the ORDER in which a pixel's fp32 contributions are added — the
+// reference adds accrad/spp sample by sample (:451-:452), here every lane sums the contributions of the samples it happened to trace and the S partial sums are added at
+// the end — a reassociation, relative 1e-6 of the pixel value, far inside the fast-math tolerance; the strict variant
+// above keeps the reference's order.  It is deterministic: a wave's schedule depends on nothing outside the wave, and
 // the pixels a wave owns are the same for every tiling the host selects it for (pathtrace.hip).
 #pragma once
 #include "pathtrace_kernel.h"
@@ -52,7 +55,7 @@ namespace mc {
 namespace pt {
 
 constexpr uint32_t kPoolEntryFloats = 8;     // {rd.x, rd.y, rd.z, t | id (-1: nothing to trace), key0 = samp * maxDepth, rnd.x, rnd.y of key0}
-constexpr uint32_t kPoolRecordStride = 16;   // floats per staged record: {geo.xyz, p (fast: 1 / p) | colour.rgb, material + 256 * emits | emission.xyz, RN(1 / p) (fast: p)}
+constexpr uint32_t kPoolRecordStride = 16;   // floats per staged record: {geo.xyz, p (fast: 1 / p) | colour.rgb, material + 256 * emits | emission.xyz, RN(1 / p) (fast: p) | fast: colour.rgb / p, the same integer bits}
 constexpr uint32_t kPoolRecordFloats = 9u * kPoolRecordStride;
 constexpr uint32_t kPoolStashFloats = 128u * kPoolEntryFloats;     // per wave: 64/S pixels x 2 batches x S entries
 constexpr uint32_t kPoolResultBatches = 4;                         // strict: result ring of 4 batches per pixel, 3 planes (x, y, z)
