@@ -259,26 +259,27 @@ struct WaveTime {};
 #ifndef MC_PT_FAST_PLANES_ONE_RCP   // fast math: one division for the three slab tests (intersect_slab)
 #define MC_PT_FAST_PLANES_ONE_RCP 1
 #endif
-#ifndef MC_PT_EXP_G
-#define MC_PT_EXP_G 1
+// Fast-math forms that can be switched off one by one for A/B measurements (`make exp EXP_NAME=x EXP_FLAGS=-D<macro>=0`, tools/time_libs.py):
+#ifndef MC_PT_FAST_TANGENT_ONE_RSQ      // light sample: sin_a / |tangent| as one A * rsq(A * B)
+#define MC_PT_FAST_TANGENT_ONE_RSQ 1
 #endif
-#ifndef MC_PT_EXP_PID
-#define MC_PT_EXP_PID 1
+#ifndef MC_PT_FAST_PLANE_ID_FROM_SIGN   // slab winner's id from constant selects and the sign of its d_a
+#define MC_PT_FAST_PLANE_ID_FROM_SIGN 1
 #endif
-#ifndef MC_PT_GENERIC_PREFETCH
+#ifndef MC_PT_FAST_FRAME_NO_CROSS       // light sample: a t1 + b t2 + c sw without the cross product
+#define MC_PT_FAST_FRAME_NO_CROSS 1
+#endif
+#ifndef MC_PT_FAST_LIGHT_DET_ONLY       // shadow_visible_disjoint: the light's own root test is det >= 0
+#define MC_PT_FAST_LIGHT_DET_ONLY 1
+#endif
+#ifndef MC_PT_FAST_COLOUR_OVER_P        // pool kernel: colour / p as a record row
+#define MC_PT_FAST_COLOUR_OVER_P 1
+#endif
+#ifndef MC_PT_FAST_OCC_MINUS_R2         // pool kernel: |c - x|^2 - r^2 formed once per bounce
+#define MC_PT_FAST_OCC_MINUS_R2 1
+#endif
+#ifndef MC_PT_GENERIC_PREFETCH          // generic kernel reading the scene from memory: next sphere record fetched ahead
 #define MC_PT_GENERIC_PREFETCH 1
-#endif
-#ifndef MC_PT_EXP_FRAME
-#define MC_PT_EXP_FRAME 1
-#endif
-#ifndef MC_PT_EXP_LIGHTHIT
-#define MC_PT_EXP_LIGHTHIT 1
-#endif
-#ifndef MC_PT_EXP_COLP
-#define MC_PT_EXP_COLP 1
-#endif
-#ifndef MC_PT_EXP_OCR
-#define MC_PT_EXP_OCR 1
 #endif
 
 constexpr float kEps = 1e-4f, kTriEps = 1e-7f, kInf = 1e20f;   // pathTracer.comp:103-105
@@ -408,15 +409,15 @@ __device__ __forceinline__ int intersect_slab(const HotSlab& h, v3 o, v3 d, floa
             num[a] = (pos ? h.W_pos[a] : h.W_negm[a]) - oa; den[a] = da; pid[a] = pos ? 2 * a + 1 : 2 * a;
         }
         float bn = num[0], bd = den[0];
-        int bid = MC_PT_EXP_PID ? 1 : pid[0];
+        int bid = MC_PT_FAST_PLANE_ID_FROM_SIGN ? 1 : pid[0];
 #pragma unroll
         for (int a = 1; a < 3; a++) {
             const bool nearer = __builtin_fabsf(num[a]) * __builtin_fabsf(bd) < __builtin_fabsf(bn) * __builtin_fabsf(den[a]);
-            bn = nearer ? num[a] : bn; bd = nearer ? den[a] : bd; bid = nearer ? (MC_PT_EXP_PID ? 2 * a + 1 : pid[a]) : bid;
+            bn = nearer ? num[a] : bn; bd = nearer ? den[a] : bd; bid = nearer ? (MC_PT_FAST_PLANE_ID_FROM_SIGN ? 2 * a + 1 : pid[a]) : bid;
         }
         // (the winner's id 2a + (d_a > 0): the odd id of its axis, less the sign bit of its d_a — two selects of constants and two
         // integer operations instead of three selects, two ORs and two selects of the ids)
-        if (MC_PT_EXP_PID) bid ^= (int)(dm::as_uint(bd) >> 31);
+        if (MC_PT_FAST_PLANE_ID_FROM_SIGN) bid ^= (int)(dm::as_uint(bd) >> 31);
         const float dd = dm::fdiv<Fast>(bn, bd);
         if constexpr (Closed) { t = dd; id = bid; }
         else if (__builtin_fabsf(bd) > h.tri_eps && dd < t) { t = dd; id = bid; }
@@ -512,7 +513,7 @@ __device__ __forceinline__ bool shadow_visible_disjoint(const HotSlab& h, v3 d, 
         const float det = OccR2 ? b[i] * b[i] - occ[i] : (b[i] * b[i] - occ[i]) + h.r2[i];
         // (the ray is aimed INTO the light's cone, :408-:413: its line meets the light by construction and the root :319-:327 keep lies
         // ahead — only det >= 0 is tested for it: the rim of the cone, where rounding decides, and a NaN direction, which must not pass)
-        if (MC_PT_EXP_LIGHTHIT && i == li) { hit[i] = det >= 0.0f; continue; }
+        if (MC_PT_FAST_LIGHT_DET_ONLY && i == li) { hit[i] = det >= 0.0f; continue; }
         const float e = b[i] - h.eps;
         hit[i] = !(det < 0.0f) && (e > 0.0f || det > e * e);
     }
@@ -667,7 +668,7 @@ template <bool Fast> __device__ __forceinline__ v3 camera_ray(const PTArgs& a, u
 template <bool Fast> __device__ __forceinline__ v3 light_sample_direction(v3 xc, float xcc, float lr2, v3 rnd, float& cos_a_max) {
     const float inv_len = dm::inversesqrt<Fast>(xcc);
     v3 sw = xc * inv_len;                                     // :409 normalize(xc)
-    if constexpr (Fast && MC_PT_EXP_G) {
+    if constexpr (Fast && MC_PT_FAST_TANGENT_ONE_RSQ) {
         // The tangents are left UNNORMALISED — t1 = cross(axis, sw) (tangent_u before its scaling), t2 = cross(sw, t1), both of
         // length k = sqrt(q^2 + sw.z^2) — and sin_a / k is formed as one factor: sqrt(A / B) = A * rsq(A * B) with A = sin_a^2 =
         // 1 - cos_a^2, B = k^2: one transcendental where 1 / k and sin_a took two (each ~12 issue cycles among other instructions,
@@ -681,7 +682,7 @@ template <bool Fast> __device__ __forceinline__ v3 light_sample_direction(v3 xc,
         const float g = A * dm::inversesqrt<true>(A * B);
         float sphi, cphi;
         dm::sincos_angle<true>(0.0f, rnd.y, sphi, cphi);                      // :412
-        if (MC_PT_EXP_FRAME) {
+        if (MC_PT_FAST_FRAME_NO_CROSS) {
             // t1 = (z, 0, -x) or (0, -z, y) has a zero component and t2 = cross(sw, t1) = (-xy, B, -yz) or (B, -xy, -xz) carries B
             // itself, so a t1 + b t2 + c sw needs no cross product: with m = the axis component (y or x), q the other one,
             // cm = c - b m and sa = +-a:  special component = b B + c m,  the other two = sa z + q cm  and  -sa q + z cm.

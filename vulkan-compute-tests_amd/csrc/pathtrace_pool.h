@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
     __syncthreads();
     // fast math: the sphere tests of a bounce (three of the shadow ray, three of the next ray, all from the hit point x) read
     // |c_i - x|^2 - r_i^2, formed once, instead of each adding r_i^2 to its b^2 - |c_i - x|^2
-    constexpr bool kOccR2 = Fast && MC_PT_EXP_OCR;
+    constexpr bool kOccR2 = Fast && MC_PT_FAST_OCC_MINUS_R2;
     constexpr uint32_t TW = WaveTile<S>::w, TH = WaveTile<S>::h, Ring = 2u * (uint32_t)S, RRing = kPoolResultBatches * (uint32_t)S;
     HotSlab hot;
     hot.load<MC_PT_POOL_HOT_VGPR, MC_PT_POOL_HOT_W>(a.scene);   // (uniform operands: this kernel has no vector registers to spare for copies)
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                 for (int i = 0; i < 3; i++) { xcc[i] = occ[i]; if constexpr (kOccR2) occ[i] = occ[i] - hot.r2[i]; }
                 const float4* obj = reinterpret_cast<const float4*>(lds_obj + kPoolRecordStride * (uint32_t)id);   // per-lane fetch
                 // (fast: past depth 5 the colour row is the one already divided by the roulette probability)
-                const float4 o0 = obj[0], o1 = obj[(Fast && MC_PT_EXP_COLP && key > krr) ? 3 : 1];
+                const float4 o0 = obj[0], o1 = obj[(Fast && MC_PT_FAST_COLOUR_OVER_P && key > krr) ? 3 : 1];
                 const bool is_sphere = id >= 6;
                 v3 geo{o0.x, o0.y, o0.z};
                 v3 col{o1.x, o1.y, o1.z};
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                 }
                 accmat = accmat * col;                                            // :392
                 const v3 rnd{rx, ry, 0.0f};                                       // :393 (drawn at the end of the previous bounce)
-                if constexpr (Fast) { if (!MC_PT_EXP_COLP) accmat = accmat * (key > krr ? p : 1.0f); }   // :395, :397 (:396 was decided there too)
+                if constexpr (Fast) { if (!MC_PT_FAST_COLOUR_OVER_P) accmat = accmat * (key > krr ? p : 1.0f); }   // :395, :397 (:396 was decided there too)
                 else if (key > krr) accmat = divs_recip<Fast>(accmat, p, obj[2].w);
                 bool go = true;
                 {
