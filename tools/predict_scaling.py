@@ -20,9 +20,10 @@ torch.cuda.set_stream(st)
 s = st.cuda_stream
 for name in (sys.argv[1:] or ["K4", "K3"]):
     cfg = bench.CONFIGS[name]
-    W, H = cfg["W"], cfg["H"]
+    weak = cfg["scaling"] == "weak"        # weak: the image grows with N (H * N rows), every rank keeps its N = 1 share
     base = None
     for n in (1, 2, 4, 8):
+        W, H = cfg["W"], cfg["H"] * (n if weak else 1)
         worst = 0.0
         for rank in sorted({0, n - 1, n // 2}):
             if cfg["kind"] == "pt":
@@ -49,4 +50,5 @@ for name in (sys.argv[1:] or ["K4", "K3"]):
             e1.record(); torch.cuda.synchronize()
             worst = max(worst, e0.elapsed_time(e1) / reps)
         base = base or worst
-        print(f"{name}  N={n}  slowest of ranks 0 / N/2 / N-1: {worst:10.2f} ms   T1 / (N T_N) = {base / (n * worst):.3f}", flush=True)
+        eff = base / worst if weak else base / (n * worst)
+        print(f"{name}  N={n}  slowest of ranks 0 / N/2 / N-1: {worst:10.2f} ms   {'T1 / T_N' if weak else 'T1 / (N T_N)'} = {eff:.3f}", flush=True)
