@@ -843,7 +843,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
         v3 oc0[3];
 #pragma unroll
         for (int i = 0; i < 3; i++) { oc0[i] = v3{a.cam_oc[i][0], a.cam_oc[i][1], a.cam_oc[i][2]}; occ[i] = a.cam_occ[i]; }
-        if (a.max_depth != 0u) id = intersect_slab<Fast>(hot, ro, rd, t, false, occ, oc0);
+        if (a.max_depth != 0u) id = intersect_slab<Fast, Box>(hot, ro, rd, t, false, occ, oc0);   // (Box: closed-box form, see intersect_slab)
     }
     MC_WT(7);   // ray generation + the camera ray's intersection
     for (uint32_t depth = 0; depth < a.max_depth; depth++) {              // :367
@@ -925,7 +925,9 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 MC_WT(1);   // light sample: cone, basis, direction
                 bool reached;                                             // :420 shadow ray: is the nearest hit sphere i?
                 if constexpr (Slab) {
-                    if (Box || sc.nee_skip_planes != 0u) reached = shadow_reaches_sphere<Fast>(hot, x, l, i, xc, occ);
+                    // (closed-box kernel, disjoint spheres — a uniform scene fact: the root-free test of the sample-pool kernel)
+                    if (Box && sc.spheres_disjoint != 0u) reached = shadow_visible_disjoint<false>(hot, l, i, xoc, occ);
+                    else if (Box || sc.nee_skip_planes != 0u) reached = shadow_reaches_sphere<Fast>(hot, x, l, i, xc, occ);
                     else reached = intersect_slab<Fast>(hot, x, l, tne, false) == np + i;
                 } else {
                     reached = intersect<Fast, NP, NS, Slab, Prec>(sc, uobj, x, l, tne, false) == np + i;
@@ -972,7 +974,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
 #pragma unroll
                     for (int i = 0; i < 3; i++) { xoc[i] = v3{hot.c[i][0], hot.c[i][1], hot.c[i][2]} - ro; occ[i] = dot(xoc[i], xoc[i]); }
                 }
-                id = intersect_slab<Fast>(hot, ro, rd, t, false, occ, xoc);
+                id = intersect_slab<Fast, Box>(hot, ro, rd, t, false, occ, xoc);
             }
             MC_WT(6);   // intersection of the next depth
         }
