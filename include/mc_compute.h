@@ -114,16 +114,16 @@ enum {
  * fast-math tolerance, and only the sample-parallel widths of ONE kernel are bit-identical to each other. */
 enum {
     MC_PT_GENERIC_KERNEL = 1u << 0, /* never use the axis-aligned-slab specialisation of the plane test */
-    MC_PT_KERNEL_REGROUP = 1u << 1, /* DIAGNOSTIC library only (make regroup -> lib/libmc_compute_regroup.so): the lane-     */
-                                    /* regrouping scheduler (csrc/pathtrace_regroup.h), measured slower than the default     */
-                                    /* kernels; the shipped library returns MC_ERR_UNSUPPORTED for this flag      */
+    /* bit 1 is reserved (rounds 2-3: a lane-regrouping experiment, removed); reserved bits -> MC_ERR_INVALID_ARGUMENT */
     MC_PT_NO_BOX_KERNEL = 1u << 2,  /* fast math: never use the closed-box specialisations (compile-time scene facts, the     */
                                     /* sample-pool kernel); the general fast slab kernel runs instead (A/B measurements)      */
     MC_PT_NO_POOL_KERNEL = 1u << 3, /* fast math: never use the sample-pool kernel (csrc/pathtrace_pool.h); the round-        */
                                     /* synchronous closed-box kernel runs instead                                            */
     MC_PT_SCENE_IN_LDS = 1u << 4,   /* generic scenes: every block stages the object records into LDS (the automatic choice   */
-    MC_PT_SCENE_IN_MEMORY = 1u << 5 /* for small scenes) / the kernel reads them where they lie (large scenes); strict math:  */
+    MC_PT_SCENE_IN_MEMORY = 1u << 5,/* for small scenes) / the kernel reads them where they lie (large scenes); strict math:  */
                                     /* bit-identical either way                                                             */
+    MC_PT_NO_FAST_GUARD = 1u << 6   /* MEASUREMENTS only: run MC_PT_MATH_FAST even on a scene the host classifies as outside the */
+                                    /* fast tolerance (MC_PT_SCENE_LIGHT_ENCLOSED), which is otherwise rendered strict          */
 };
 #define MC_PT_FORCE_S(s) ((uint32_t)(s) << 8) /* force the sample-parallel width: 1, 4 or 16 (0 = automatic) */
 /* Sphere-test precision branch of pathTracer.comp:132-256.  The reference compiles every variant OUT
@@ -189,12 +189,37 @@ int mc_pathtrace_render_rgba8(mc_context* ctx, const mc_pathtrace_params* p, con
  * margin: shadow rays (pathTracer.comp:420) skip the plane tests.  Both specialisations are bit-exact;
  * every other scene takes the generic kernel.  Bit 2 (MC_PT_SCENE_SPHERES_DISJOINT) — slab scenes: the three spheres are pairwise
  * disjoint with a margin; only then does MC_PT_MATH_FAST take the sample-pool kernel, which orders the spheres a shadow ray meets by
- * the projections of their centres (strict math does not depend on it). */
+ * the projections of their centres (strict math does not depend on it).  Bit 3 (MC_PT_SCENE_LIGHT_ENCLOSED) — any scene: an
+ * emissive sphere lies inside a non-emissive opaque sphere or pokes out of it by less than its own radius.  Such a light is seen only
+ * through near-ties between the two surfaces (pathTracer.comp:325,333,420), which fast math decides differently from the reference
+ * arithmetic far more often than its tolerance allows: an MC_PT_MATH_FAST request for such a scene is RENDERED WITH
+ * THE STRICT KERNELS (bit-identical to the oracle), never silently outside the bound. */
 #define MC_PT_SCENE_SLAB 1u
 #define MC_PT_SCENE_LIGHTS_INSIDE 2u
 #define MC_PT_SCENE_SPHERES_DISJOINT 4u   /* slab scenes: the three spheres are pairwise disjoint (the fast sample-pool kernel's premise) */
+#define MC_PT_SCENE_LIGHT_ENCLOSED 8u     /* a light (all but) enclosed by an opaque sphere: fast math requests are rendered strict */
 int mc_pathtrace_scene_class(const float* planes, uint32_t n_planes, const float* spheres, uint32_t n_spheres,
                              uint32_t* out_class);
+
+/* Which kernel mc_pathtrace_render* will run for a request — decided on the host from the parameters and the scene alone (no
+ * device, usable without a GPU).  In MC_PT_MATH_FAST different kernels are different instruction sequences (equal within the
+ * tolerance, not bit for bit), so an N-GPU or progressive caller that needs tiles / ranges to compose bit-identically asserts
+ * that every part reports the same `kernel` and `lanes_per_pixel` as the whole image does.  Validates like the render call. */
+enum {
+    MC_PT_KERNEL_GENERIC = 0,        /* any scene, records staged into LDS (pathTracer.comp:112-131 as written)              */
+    MC_PT_KERNEL_SLAB = 1,           /* 6 axis-aligned planes + 3 spheres, round-synchronous                                 */
+    MC_PT_KERNEL_BOX = 3,            /* closed-box scene facts at compile time, round-synchronous (fast math)                */
+    MC_PT_KERNEL_POOL = 4,           /* the sample-pool kernel (the default for the reference scene, both math modes)        */
+    MC_PT_KERNEL_GENERIC_MEMORY = 5  /* any scene, records read from memory (large scenes)                                   */
+};
+typedef struct mc_pathtrace_kernel_info {
+    uint32_t kernel;          /* MC_PT_KERNEL_*                                                                             */
+    uint32_t lanes_per_pixel; /* sample-parallel width S: lanes of a wave that share a pixel (1, 4 or 16)                    */
+    uint32_t math_mode;       /* the mode that RUNS: MC_PT_MATH_STRICT for a fast request on an MC_PT_SCENE_LIGHT_ENCLOSED scene */
+    uint32_t launches;        /* kernel launches per call (2: a ragged sample count in the round-synchronous kernels)        */
+} mc_pathtrace_kernel_info;
+int mc_pathtrace_select_kernel(const mc_pathtrace_params* p, const float* planes, uint32_t n_planes, const float* spheres,
+                               uint32_t n_spheres, mc_pathtrace_kernel_info* out);
 
 /* ---- stream / tiling helpers ------------------------------------------------------------------ */
 int mc_context_synchronize(mc_context* ctx);
@@ -232,26 +257,6 @@ int mc_multi_pathtrace_render(mc_multi* m, const mc_pathtrace_params* p, const f
 int mc_multi_mandelbrot_render_rgba8(mc_multi* m, const mc_mandelbrot_params* p, uint8_t* out_rgba8);
 int mc_multi_pathtrace_render_rgba8(mc_multi* m, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
                                     const float* spheres, uint32_t n_spheres, uint8_t* out_rgba8);
-
-/* ---- device self-tests used by the parity suite (evaluate device functions over arrays) --------- */
-/* fn: 0 mc_sin, 1 mc_cos, 2 mc_log2, 3 mc_exp2, 4 pow(x,0.45), 5 inversesqrt, 6 sqrt, 7 1/x,
- * 8/9 sin/cos via the fused mc_sincos; fast=1 evaluates the MC_PT_MATH_FAST variants instead. */
-int mc_test_math(mc_context* ctx, int fn, int fast, const float* in, float* out, size_t n);
-/* Strict (a[3i], a[3i+1], a[3i+2]) / s[i] as the path tracer divides a colour by a probability, by pi, by the sample count (short
- * division inside its window, IEEE expansion outside); with_y != 0: the reciprocal RN(1/s) is supplied instead of computed. */
-int mc_test_div3(mc_context* ctx, int with_y, const float* a, const float* s, float* out, size_t n);
-/* Strict fn 5 / 6 / 7 (and the guarded short reciprocal) over EVERY fp32 bit pattern first_bits .. first_bits+count-1, compared on
- * the device with the compiler's IEEE expansion: *mismatches (NaN == NaN), *checksum = sum of (result_bits ^ (bits * 0x9E3779B1))
- * mod 2^64 for a host-side comparison, *first_mismatch = lowest offending pattern (0xffffffff if none). */
-int mc_test_math_sweep(mc_context* ctx, int fn, uint32_t first_bits, uint64_t count, uint64_t* mismatches, uint64_t* checksum,
-                       uint32_t* first_mismatch);
-/* rand01 (pathTracer.comp:107-110) over n keys (x,y,z) -> 3 floats each. */
-int mc_test_rand01(mc_context* ctx, const uint32_t* xyz, float* out, size_t n);
-/* two-float primitives (emulateDouble.h.glsl): op 0 ds_add, 1 ds_sub, 2 ds_mul, 3 ds_compare, 4 ds_sqrt(a), 5 df64_add,
- * 6 df64_mult, 7 df64_sqrt(a), 8 ds_twoProd(a.hi,b.hi), 9 ds_div, 10 twoDiff(a.hi,b.hi), 11 (df64_eq, df64_neq) as 0/1,
- * 12 ds_mul with the one-fma error term (the two-float Mandelbrot's fast block; equals op 2 for |hi| in [2^-50, 2^60));
- * n pairs of (hi,lo). */
-int mc_test_ds_op(mc_context* ctx, int op, const float* a, const float* b, float* out, size_t n);
 
 #ifdef __cplusplus
 }

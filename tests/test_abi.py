@@ -21,6 +21,17 @@ def test_library_exports_every_declared_symbol(B):
     assert L.mc_abi_version() == 1
 
 
+def test_test_hooks_live_in_their_own_library(B):
+    """The device self-test hooks (include/mc_compute_test.h) are test infrastructure: exported by libmc_compute_test.so, absent
+    from the product library and from the header a binding of the reference reads."""
+    names = B.declared_test_symbols()
+    assert len(names) == 5
+    T = B.test_lib()
+    assert not [n for n in names if not hasattr(T, n)]
+    assert not [n for n in names if hasattr(B.lib(), n)], "test hooks exported by the product library"
+    assert not [n for n in B.declared_symbols() if n.startswith("mc_test_")]
+
+
 def test_param_struct_layouts(B, tmp_path):
     """The header is plain C (gcc -std=c99 compiles it) and the ctypes mirrors have the compiler's layout."""
     src = tmp_path / "layout.c"
@@ -218,3 +229,51 @@ def test_scene_classification_host_logic(B, O):
     out = C.c_uint32()
     fn = B.lib().mc_pathtrace_scene_class
     assert fn(None, 6, None, 0, C.byref(out)) == 1 and fn(None, 0, None, 0, None) == 1   # MC_ERR_INVALID_ARGUMENT
+
+
+# The scene tools/fuzz_fast.py found in round 3 (seed 42): light sphere 1 pokes 0.0099 out of the diffuse sphere 2.
+ENCLOSED_LIGHT_PLANES = [[-1.0, 0.0, 0.0, 3.028991460800171, 0.0, 0.0, 0.0, 0.0, 0.35169631242752075, 0.34318363666534424, 0.3693005442619324, 1.0], [1.0, 0.0, 0.0, 2.2744364738464355, 0.0, 0.0, 0.0, 0.0, 0.5065174102783203, 0.6979612708091736, 0.37550920248031616, 1.0], [0.0, 1.0, 0.0, 1.999233365058899, 0.0, 0.0, 0.0, 0.0, 0.6414122581481934, 0.12747998535633087, 0.9308241009712219, 1.0], [0.0, -1.0, 0.0, 2.2489571571350098, 0.0, 0.0, 0.0, 0.0, 0.27769729495048523, 0.8655855655670166, 0.46052539348602295, 1.0], [0.0, 0.0, -1.0, 3.2203400135040283, 0.0, 0.0, 0.0, 0.0, 0.26442480087280273, 0.9096760153770447, 0.43677741289138794, 1.0], [0.0, 0.0, 1.0, 8.45179557800293, 0.0, 0.0, 0.0, 0.0, 0.7169037461280823, 0.9640538692474365, 0.3762871026992798, 2.0]]
+ENCLOSED_LIGHT_SPHERES = [[1.5096889734268188, 0.9952030181884766, 0.4704371988773346, 0.47152015566825867, 0.0, 0.0, 0.0, 0.0, 0.2772885859012604, 0.8747192621231079, 0.6441940665245056, 1.0], [0.001190655748359859, 0.8120155930519104, -1.2923463582992554, 0.13228453695774078, 55.296485900878906, 51.39237976074219, 106.38571166992188, 0.0, 0.0, 0.0, 0.0, 1.0], [-0.2052173614501953, -0.06327978521585464, -1.4568519592285156, 1.0365451574325562, 0.0, 0.0, 0.0, 0.0, 0.13128790259361267, 0.2444259524345398, 0.9829038977622986, 1.0]]
+
+
+def test_fast_math_guard_classification_and_kernel_query(B, O):
+    """Bit 3 of the scene class — a light (all but) enclosed by an opaque sphere — and what mc_pathtrace_select_kernel reports:
+    a fast request on such a scene runs the STRICT kernels (tests/test_gpu_fast_scenes.py renders it against the oracle)."""
+    ENC = B.PT_SCENE_LIGHT_ENCLOSED
+    P, S = np.float32(ENCLOSED_LIGHT_PLANES), np.float32(ENCLOSED_LIGHT_SPHERES)
+    assert B.pathtrace_scene_class(P, S) & ENC
+    assert B.pathtrace_scene_class(O.DEFAULT_PLANES, O.DEFAULT_SPHERES) & ENC == 0
+    fast = B.pathtrace_params(300, 200, 256, math_mode=B.PT_MATH_FAST)
+    k = B.pathtrace_select_kernel(fast, P, S)
+    assert k.math_mode == B.PT_MATH_STRICT and k.kernel == B.PT_KERNEL_POOL and k.launches == 1
+    forced = B.pathtrace_params(300, 200, 256, math_mode=B.PT_MATH_FAST, flags=B.PT_NO_FAST_GUARD)
+    assert B.pathtrace_select_kernel(forced, P, S).math_mode == B.PT_MATH_FAST
+    # the criterion: how far the light pokes out of the opaque sphere, against its own radius
+    big, light = S[2], S[1]
+    axis = (light[:3] - big[:3]) / np.linalg.norm(light[:3] - big[:3])
+
+    def with_gap(out, material=1.0, emissive_big=False):
+        s = S.copy()
+        s[1, :3] = big[:3] + axis * (big[3] - light[3] + out)
+        s[2, 11] = material
+        if emissive_big:
+            s[2, 4:7] = 1.0
+        return B.pathtrace_scene_class(P, s) & ENC
+    assert with_gap(-0.3) and with_gap(0.0) and with_gap(0.5 * light[3]) and with_gap(0.99 * light[3])
+    assert not with_gap(1.05 * light[3]) and not with_gap(2 * light[3] + 0.5)
+    assert with_gap(0.01, material=2.0) and not with_gap(0.01, material=3.0)     # inside a mirror: yes; inside glass: well conditioned
+    assert not with_gap(0.01, emissive_big=True)                                  # two lights
+    # any scene, not only slab ones (the generic kernels have the same fast mode)
+    assert B.pathtrace_scene_class(P[[2, 3, 0, 1, 4, 5]], S) == ENC
+    # the reference scene: pool kernel in both modes, the round-synchronous kernels for what the pool kernel does not take
+    q = B.pathtrace_params(900, 600, 500, math_mode=B.PT_MATH_FAST)
+    k = B.pathtrace_select_kernel(q)
+    assert (k.kernel, k.lanes_per_pixel, k.math_mode, k.launches) == (B.PT_KERNEL_POOL, 16, B.PT_MATH_FAST, 1)
+    q.flags = B.PT_NO_POOL_KERNEL
+    k = B.pathtrace_select_kernel(q)
+    assert (k.kernel, k.lanes_per_pixel, k.launches) == (B.PT_KERNEL_BOX, 16, 2)          # 500 = 31 x 16 + 4: a second, narrower launch
+    q.flags = B.PT_GENERIC_KERNEL
+    assert B.pathtrace_select_kernel(q).kernel == B.PT_KERNEL_GENERIC
+    q.flags = 2
+    with pytest.raises(B.McError):
+        B.pathtrace_select_kernel(q)

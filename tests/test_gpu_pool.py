@@ -201,3 +201,29 @@ def test_pool_kernel_scene_variants_within_tolerance(ctx, B, O, case):
     p999 = float(np.percentile(np.sqrt((d ** 2).sum(-1)), 99.9))
     print(f"{case}: pool vs oracle(libm): rmse {rmse:.4f}  p99.9 L2 {p999:.3f}  mean diff {d.mean():+.5f}")
     assert rmse <= 0.5 and p999 <= 4.0 and abs(d.mean()) < 0.05
+
+
+def test_a_tripped_scheduler_bound_is_reported_not_stored_silently(B):
+    """the pool kernels bound their scheduling loop; if a defect ever exhausted the bound the image would be incomplete.
+    A diagnostic build whose bound is FIVE iterations must make the blocking entry point fail (status word -> MC_ERR_HIP) instead of
+    returning a partial image with MC_OK; the shipped library renders the same request fine."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    pkg = os.path.join(ROOT, "vulkan-compute-tests_amd")
+    subprocess.check_call(["make", "-s", "-C", pkg, "exp", "EXP_NAME=bound", "EXP_FLAGS=-DMC_PT_POOL_TEST_BOUND=5"])
+    child = ("import sys; sys.path.insert(0, %r)\n"
+             "import __graft_entry__ as e\n"
+             "B = e.load_package().bindings\n"
+             "with B.Context(0) as ctx:\n"
+             "    try:\n"
+             "        ctx.pathtrace(B.pathtrace_params(16, 8, 64, math_mode=B.PT_MATH_FAST))\n"
+             "        print('NO ERROR')\n"
+             "    except B.McError as err:\n"
+             "        print('STATUS', err.status, err)\n"
+             "    ctx.pathtrace(B.pathtrace_params(16, 8, 64, math_mode=B.PT_MATH_FAST, flags=B.PT_NO_POOL_KERNEL))\n"
+             "    print('ROUNDS OK')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True,
+                       env=dict(os.environ, MC_LIB_PATH=os.path.join(pkg, "lib", "libmc_compute_exp_bound.so")))
+    assert "STATUS 3" in r.stdout and "loop bound" in r.stdout and "ROUNDS OK" in r.stdout, r.stdout + r.stderr[-2000:]

@@ -79,81 +79,30 @@ def test_parallel_png_large_image_is_faster_or_equal_size_sane(H, O):
     assert len(b) < len(a) * 1.02 + 4096
 
 
-# ---- the reference-compatible encoder (host/pngReference.cpp): the BYTES the reference's codec writes -----------------------
-@pytest.fixture(scope="module")
-def HR(H):
-    H.mcu_png_encode_reference.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_size_t)]
-    return H
-
-
-def encode_reference(H, img):
-    img = np.ascontiguousarray(img, np.uint8)
-    h, w = img.shape[:2]
-    out, n = C.POINTER(C.c_ubyte)(), C.c_size_t(0)
-    rc = H.mcu_png_encode_reference(img.ctypes.data_as(C.c_void_p), w, h, C.byref(out), C.byref(n))
-    if rc:
-        return None
-    data = C.string_at(out, n.value)
-    H.mcu_free(out)
-    return data
-
-
+# ---- north_star's "bit-identical PNG": identical RGBA8 pixels + the REFERENCE'S OWN codec (INTEGRATION.md route B) ----------------
+# The apps write standard PNGs of exactly the reference's pixels through their own parallel writer; they do not re-implement the
+# reference's vendored third-party codec (round 3 carried a source-derived port of it, removed in round 4).  The byte contract is
+# met where the reference tree keeps its lodepng::encode call: the codec built from the reference sources where they lie
+# (oracle/_ref) turns the pixels this library produces into the pinned bytes.
 def opaque(rgb):
     return np.ascontiguousarray(np.concatenate([rgb, np.full(rgb.shape[:2] + (1,), 255, np.uint8)], -1))
 
 
-def reference_encoder_cases(O):
-    rng = np.random.default_rng(1)
-    cases = {"noise": opaque(rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)),
-             "1x1": opaque(np.array([[[10, 20, 30]]], np.uint8)),
-             "grey ramp (8-bit grey)": opaque(np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 3, 2).repeat(40, 0)),
-             "black / white (1-bit grey)": opaque((rng.integers(0, 2, (33, 45, 1), dtype=np.uint8) * 255).repeat(3, 2)),
-             "4-bit grey": opaque((rng.integers(0, 16, (20, 31, 1), dtype=np.uint8) * 17).repeat(3, 2)),
-             "2-bit grey": opaque((rng.integers(0, 4, (20, 31, 1), dtype=np.uint8) * 85).repeat(3, 2)),
-             "all zero": opaque(np.zeros((100, 300, 3), np.uint8))}
-    for n_col, shape in ((2, (17, 23)), (5, (50, 70)), (16, (40, 40)), (17, (40, 40)), (100, (80, 90)), (256, (64, 64)), (257, (64, 64))):
-        pal = rng.integers(0, 256, (n_col, 3), dtype=np.uint8)
-        idx = rng.integers(0, n_col, shape)
-        idx.flat[:n_col] = np.arange(n_col)               # every colour present
-        cases[f"{n_col} colours"] = opaque(pal[idx])
-    cases["3 colours, 5 pixels (too few for a palette)"] = opaque(np.array([[[1, 2, 3], [4, 5, 6], [7, 8, 9], [1, 2, 3], [4, 5, 6]]], np.uint8))
-    g = (np.outer(np.linspace(0, 1, 200), np.linspace(0, 1, 300)) * 255).astype(np.uint8)
-    cases["smooth rgb"] = opaque(np.stack([g, g[::-1], 255 - g], -1))
-    _, lut_u8 = O.mandel_lut(128)
-    cases["mandelbrot 256x256 M=128 (palette)"] = np.ascontiguousarray(lut_u8[O.mandelbrot_iters(256, 256, 128)])
-    _, lut_u8 = O.mandel_lut(1000)
-    cases["mandelbrot 800x600 M=1000 (several deflate blocks)"] = np.ascontiguousarray(lut_u8[O.mandelbrot_iters(800, 600, 1000)])
-    return cases
-
-
-def test_reference_compatible_encoder_matches_lodepng(HR, O):
-    """Byte for byte against the reference's own codec (oracle/_ref, built from the reference sources where they lie) over the
-    colour models, bit depths, filter choices and block counts the encoder can produce."""
-    if O.ref_lodepng() is None:
-        pytest.skip("oracle/_ref/liblodepng_ref.so not built (needs the reference checkout)")
-    for name, img in reference_encoder_cases(O).items():
-        mine = encode_reference(HR, img)
-        assert mine is not None and mine == O.ref_png_encode(img, img.shape[1], img.shape[0]), name
-        assert np.array_equal(decode(mine), img), name
-
-
-def test_reference_compatible_encoder_golden_bytes(HR, O):
-    """Without the reference at hand: the SHA-256 pinned from the reference's codec for the oracle's default Mandelbrot image
-    (tests/golden/make_golden.py), and the reference's README image — 900 x 600, 1 057 515 bytes — reproduced from its pixels."""
+def test_reference_codec_on_these_pixels_gives_the_pinned_bytes(H, O):
+    """oracle/_ref (the reference's lodepng, compiled where it lies) on the oracle's 256 x 256 M = 128 Mandelbrot pixels and on the
+    decoded README image reproduces the SHA-256 pins / the README file's 1 057 515 bytes; the apps' own writer round-trips the same
+    pixels (another valid byte stream)."""
     import hashlib
     from conftest import GOLDEN
+    if O.ref_lodepng() is None:
+        pytest.skip("oracle/_ref/liblodepng_ref.so not built (needs the reference checkout)")
     _, lut_u8 = O.mandel_lut(128)
     img = np.ascontiguousarray(lut_u8[O.mandelbrot_iters(256, 256, 128)])
     golden = open(os.path.join(GOLDEN, "mandelbrot_256_M128_lodepng.sha256")).read().split()[0]
-    assert hashlib.sha256(encode_reference(HR, img)).hexdigest() == golden
+    assert hashlib.sha256(O.ref_png_encode(img, 256, 256)).hexdigest() == golden
+    assert np.array_equal(decode(encode(H, img, 4)), img)
     rgb = np.load(os.path.join(GOLDEN, "readme_image_rgb.npz"))
     rgb = rgb[list(rgb.keys())[0]]
-    png = encode_reference(HR, opaque(rgb))
+    png = O.ref_png_encode(opaque(rgb), rgb.shape[1], rgb.shape[0])
     assert len(png) == 1057515
     assert hashlib.sha256(png).hexdigest() == open(os.path.join(GOLDEN, "readme_image_png.sha256")).read().split()[0]
-
-
-def test_reference_compatible_encoder_refuses_alpha(HR):
-    img = np.full((4, 4, 4), 255, np.uint8)
-    img[2, 3, 3] = 254
-    assert encode_reference(HR, img) is None              # the apps then take the parallel writer (ComputeApp::writePng)

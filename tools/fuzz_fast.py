@@ -19,7 +19,7 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 import __graft_entry__ as entry  # noqa: E402
 
 
-def scene(rng, O):
+def scene(rng, O, enclose=False):
     planes = O.DEFAULT_PLANES.copy().reshape(6, 12)
     spheres = O.DEFAULT_SPHERES.copy().reshape(3, 12)
     planes[:, 3] *= rng.uniform(0.85, 1.25, 6).astype(np.float32)
@@ -40,18 +40,22 @@ def scene(rng, O):
         spheres[i, 11] = 1.0
         spheres[i, 3] = np.float32(rng.uniform(0.05, 0.4))
         spheres[i, 0:3] = rng.uniform(lo + 0.4, hi - 0.4).astype(np.float32)
-    # A light (all but) ENCLOSED by an opaque sphere — the case found had 0.01 of it poking out — is seen only through grazing
-    # decisions between the two surfaces and self-intersection leaks, each worth a firefly of the light's full emission: the image is
-    # made of last-bit effects, the oracle's own two evaluations (mc math / libm) drift apart (RMSE 0.17 where 0.06 is usual) and no
-    # reordering of the arithmetic can stay within a tolerance of it.  Found by this campaign (seed 42: fast kernels of every kind
-    # 2-4 % of the pixels off, RMSE 3.6; the strict kernels bit-exact); such scenes are redrawn.
-    for i in range(3):
-        if spheres[i, 4:7].any():
-            for j in range(3):
-                if j != i and not spheres[j, 4:7].any() and spheres[j, 11] != 3.0:
-                    gap = np.linalg.norm(spheres[i, 0:3] - spheres[j, 0:3]) + spheres[i, 3] - spheres[j, 3]
-                    if gap < 0.05:
-                        return scene(rng, O)
+    # A light (all but) ENCLOSED by an opaque sphere is outside what fast math can hold (found by this campaign in round 3, seed 42:
+    # fast kernels of every kind 2-4 % of the pixels off, RMSE 3.6): the host classifies such scenes (scene class bit 3) and renders
+    # them with the strict kernels — main() expects the oracle's bits there.  `enclose` aims a share of the scenes AT that boundary:
+    # a light placed so that it pokes out of an opaque sphere by -0.5 ... 3 of its own radii (the criterion's margin is 1).
+    if enclose and rng.random() < 0.35:
+        lights = [i for i in range(3) if spheres[i, 4:7].any()]
+        darks = [j for j in range(3) if not spheres[j, 4:7].any()]
+        if lights and darks:
+            i, j = int(rng.choice(lights)), int(rng.choice(darks))
+            spheres[j, 3] = np.float32(rng.uniform(0.5, 1.1))
+            if spheres[j, 11] == 3.0:
+                spheres[j, 11] = float(rng.choice([1, 2]))
+            spheres[j, 0:3] = rng.uniform(lo + 0.9, hi - 0.9).astype(np.float32)
+            u = rng.normal(size=3); u /= np.linalg.norm(u)
+            out = rng.uniform(-0.5, 3.0) * spheres[i, 3]
+            spheres[i, 0:3] = (spheres[j, 0:3] + u * (spheres[j, 3] - spheres[i, 3] + out)).astype(np.float32)
     return planes, spheres
 
 
@@ -59,24 +63,33 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--enclose", action="store_true", help="aim a third of the scenes at the enclosed-light boundary (scene class bit 3)")
     args = ap.parse_args()
     B, O = entry.load_package().bindings, entry.load_oracle()
     ctx = B.Context(0)
     rng = np.random.default_rng(args.seed)
-    n = {"cases": 0, "closed_box": 0, "disjoint": 0}
+    n = {"cases": 0, "closed_box": 0, "disjoint": 0, "guarded": 0}
     worst = {"frac_far": 0.0, "mean": 0.0}
     bad = []
     t0 = last = time.time()
     while time.time() - t0 < args.seconds:
-        planes, spheres = scene(rng, O)
+        planes, spheres = scene(rng, O, args.enclose)
         cls = B.pathtrace_scene_class(planes, spheres)
         W, H = int(rng.integers(8, 40)), int(rng.integers(8, 28))
         spp = int(rng.choice([16, 24, 33, 64, 100]))
         depth = int(rng.choice([12, 12, 5, 8]))
         flags = int(rng.choice([0, 0, 0, B.PT_NO_POOL_KERNEL, B.pt_force_s(16), B.pt_force_s(1)]))
         out = ctx.pathtrace(B.pathtrace_params(W, H, spp, max_depth=depth, math_mode=B.PT_MATH_FAST, flags=flags), planes=planes, spheres=spheres)
-        ref = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_LIBM, max_depth=depth)
         n["cases"] += 1
+        if cls & B.PT_SCENE_LIGHT_ENCLOSED:   # classified outside the fast tolerance: the strict kernels must have rendered it
+            n["guarded"] += 1
+            mc = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC, max_depth=depth)
+            if not np.array_equal(out.view(np.uint32), mc.view(np.uint32)) and len(bad) < 5:
+                bad.append(f"GUARDED scene not bit-identical to the oracle: class={cls} W={W} H={H} spp={spp} depth={depth} flags={flags}\n"
+                           f"planes={planes.tolist()}\nspheres={spheres.tolist()}")
+                print("SUSPECT", bad[-1], flush=True)
+            continue
+        ref = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_LIBM, max_depth=depth)
         n["closed_box"] += int(cls & 3 == 3)
         n["disjoint"] += int(cls & 4 == 4)
         d = out[..., :3].astype(np.float64) - ref[..., :3].astype(np.float64)

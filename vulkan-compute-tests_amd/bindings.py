@@ -20,11 +20,11 @@ PT_MATH_STRICT, PT_MATH_FAST = 0, 1
 MANDEL_FMA = 1
 MANDEL_ITERS_U16 = 2   # device form: d_iters is a uint16 plane (max_iter <= 65535): the multi-GPU exchange format
 PT_GENERIC_KERNEL = 1
-PT_KERNEL_REGROUP = 2   # diagnostic library only (lib/libmc_compute_regroup.so)
 PT_NO_BOX_KERNEL = 4    # fast math: the general slab kernel instead of the closed-box ones
 PT_NO_POOL_KERNEL = 8   # fast math: the round-synchronous closed-box kernel instead of the sample-pool kernel
 PT_SCENE_IN_LDS = 16    # generic scenes: records staged into LDS by every block (automatic for small scenes) ...
 PT_SCENE_IN_MEMORY = 32  # ... or read where they lie (automatic for large ones); same results
+PT_NO_FAST_GUARD = 64    # measurements only: fast math even on a scene classified PT_SCENE_LIGHT_ENCLOSED
 PT_PREC_F32, PT_PREC_FP64, PT_PREC_DS, PT_PREC_DF64 = 0, 1, 2, 3
 DS_OPS = {"add": 0, "sub": 1, "mul": 2, "compare": 3, "sqrt": 4, "df64_add": 5, "df64_mult": 6, "df64_sqrt": 7, "twoprod": 8,
           "div": 9, "twodiff": 10, "df64_eqneq": 11, "mul_fma": 12}
@@ -108,14 +108,39 @@ def lib():
         L.mc_multi_destroy.argtypes = [vp]
         L.mc_multi_mandelbrot_render.argtypes = [vp, C.POINTER(MandelbrotParams), vp, vp]
         L.mc_multi_pathtrace_render.argtypes = [vp, C.POINTER(PathtraceParams), vp, u32, vp, u32, vp]
+        _lib = L
+    return _lib
+
+
+_test_lib = None
+TEST_LIB_PATH = os.path.join(_HERE, "lib", "libmc_compute_test.so")
+TEST_HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mc_compute_test.h")
+
+
+def test_lib():
+    """Loads libmc_compute_test.so — the device self-test hooks of the parity suite (include/mc_compute_test.h).  Test
+    infrastructure: not part of the drop-in boundary, never linked by the apps."""
+    global _test_lib
+    if _test_lib is None:
+        lib()   # the product library first (the hooks link against it; with MC_LIB_PATH the diagnostic build must be the one bound)
+        if not os.path.exists(TEST_LIB_PATH):
+            raise FileNotFoundError(f"{TEST_LIB_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(TEST_LIB_PATH)
+        vp, i32 = C.c_void_p, C.c_int
         L.mc_test_math.argtypes = [vp, i32, i32, vp, vp, C.c_size_t]
         L.mc_test_div3.argtypes = [vp, i32, vp, vp, vp, C.c_size_t]
         L.mc_test_math_sweep.argtypes = [vp, i32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint32)]
         L.mc_test_rand01.argtypes = [vp, vp, vp, C.c_size_t]
         L.mc_test_ds_op.argtypes = [vp, i32, vp, vp, vp, C.c_size_t]
-        _lib = L
-    return _lib
+        _test_lib = L
+    return _test_lib
+
+
+def declared_test_symbols():
+    """Every function name include/mc_compute_test.h declares."""
+    text = re.sub(r"/\*.*?\*/", "", open(TEST_HEADER_PATH).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(mc_test_[a-z0-9_]+)\s*\(", text)))
 
 
 def _check(status, what):
@@ -181,7 +206,26 @@ def tile_rows(p):
     return int(lib().mc_tile_rows(p.row_begin, p.row_end, p.row_block, p.row_stride))
 
 
-PT_SCENE_SLAB, PT_SCENE_LIGHTS_INSIDE, PT_SCENE_SPHERES_DISJOINT = 1, 2, 4
+PT_SCENE_SLAB, PT_SCENE_LIGHTS_INSIDE, PT_SCENE_SPHERES_DISJOINT, PT_SCENE_LIGHT_ENCLOSED = 1, 2, 4, 8
+PT_KERNEL_GENERIC, PT_KERNEL_SLAB, PT_KERNEL_BOX, PT_KERNEL_POOL, PT_KERNEL_GENERIC_MEMORY = 0, 1, 3, 4, 5
+PT_KERNEL_NAMES = {0: "generic", 1: "slab", 3: "box", 4: "pool", 5: "generic_memory"}
+
+
+class PathtraceKernelInfo(C.Structure):
+    _fields_ = [("kernel", C.c_uint32), ("lanes_per_pixel", C.c_uint32), ("math_mode", C.c_uint32), ("launches", C.c_uint32)]
+
+
+def pathtrace_select_kernel(p, planes=None, spheres=None):
+    """mc_pathtrace_select_kernel: the kernel a render call with these parameters and this scene runs (no device needed)."""
+    if planes is None or spheres is None:
+        planes, spheres = default_scene()
+    planes = np.ascontiguousarray(planes, np.float32).reshape(-1, 12)
+    spheres = np.ascontiguousarray(spheres, np.float32).reshape(-1, 12)
+    out = PathtraceKernelInfo()
+    fn = lib().mc_pathtrace_select_kernel
+    fn.argtypes = [C.POINTER(PathtraceParams), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(PathtraceKernelInfo)]
+    _check(fn(C.byref(p), _ptr(planes), planes.shape[0], _ptr(spheres), spheres.shape[0], C.byref(out)), "mc_pathtrace_select_kernel")
+    return out
 
 
 def pathtrace_scene_class(planes, spheres):
@@ -296,35 +340,35 @@ class Context:
                 "sincos_c": 9}[fn]
         x = np.ascontiguousarray(x, np.float32).reshape(-1)
         out = np.empty_like(x)
-        _check(lib().mc_test_math(self._h, code, int(fast), _ptr(x), _ptr(out), x.size), "mc_test_math")
+        _check(test_lib().mc_test_math(self._h, code, int(fast), _ptr(x), _ptr(out), x.size), "mc_test_math")
         return out
 
     def test_div3(self, a, s, with_y=False):
         a = np.ascontiguousarray(a, np.float32).reshape(-1, 3)
         s = np.ascontiguousarray(s, np.float32).reshape(-1)
         out = np.empty_like(a)
-        _check(lib().mc_test_div3(self._h, int(with_y), _ptr(a), _ptr(s), _ptr(out), s.size), "mc_test_div3")
+        _check(test_lib().mc_test_div3(self._h, int(with_y), _ptr(a), _ptr(s), _ptr(out), s.size), "mc_test_div3")
         return out
 
     def test_math_sweep(self, fn, first_bits, count):
         """(mismatches vs the IEEE expansion, checksum, first mismatching pattern) over `count` consecutive bit patterns."""
         code = {"rsqrt": 5, "sqrt": 6, "rcp": 7}[fn]
         bad, chk, first = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
-        _check(lib().mc_test_math_sweep(self._h, code, first_bits, count, C.byref(bad), C.byref(chk), C.byref(first)),
+        _check(test_lib().mc_test_math_sweep(self._h, code, first_bits, count, C.byref(bad), C.byref(chk), C.byref(first)),
                "mc_test_math_sweep")
         return bad.value, chk.value, first.value
 
     def test_rand01(self, xyz):
         k = np.ascontiguousarray(xyz, np.uint32).reshape(-1, 3)
         out = np.empty(k.shape, np.float32)
-        _check(lib().mc_test_rand01(self._h, _ptr(k), _ptr(out), k.shape[0]), "mc_test_rand01")
+        _check(test_lib().mc_test_rand01(self._h, _ptr(k), _ptr(out), k.shape[0]), "mc_test_rand01")
         return out
 
     def test_ds_op(self, op, a, b):
         a = np.ascontiguousarray(a, np.float32).reshape(-1, 2)
         b = np.ascontiguousarray(b, np.float32).reshape(-1, 2)
         out = np.empty(a.shape, np.float32)
-        _check(lib().mc_test_ds_op(self._h, DS_OPS[op], _ptr(a), _ptr(b), _ptr(out),
+        _check(test_lib().mc_test_ds_op(self._h, DS_OPS[op], _ptr(a), _ptr(b), _ptr(out),
                                    a.shape[0]), "mc_test_ds_op")
         return out
 

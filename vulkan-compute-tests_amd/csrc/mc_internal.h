@@ -55,7 +55,7 @@ struct mc_context {
     int note_launch(hipStream_t s);
     int drain_launch_streams();
     // Device status word: a kernel whose scheduler trips one of its loop bounds ORs a bit in instead of spinning
-    // (pathtrace_regroup.h).  Checked — and cleared — by the blocking entry points and mc_context_synchronize().
+    // (pathtrace_pool.h: bit 1).  Checked — and cleared — by the blocking entry points and mc_context_synchronize().
     // experiment: a caller-supplied dispatch order for the Mandelbrot tiles (mc_debug_mandelbrot_tile_order; not part of the ABI)
     const void* debug_tile_order = nullptr;
     size_t debug_tile_order_n = 0;
@@ -72,6 +72,8 @@ void mandelbrot_build_lut(uint32_t max_iter, const float k_color[4], float* lut)
 int mandelbrot_lut_device(mc_context* ctx, const mc_mandelbrot_params* p, hipStream_t s, const void** d_lut);
 // pathtrace.hip
 uint32_t pathtrace_scene_class(const float* planes, uint32_t n_planes, const float* spheres, uint32_t n_spheres);
+int pathtrace_select_kernel(const mc_pathtrace_params* p, const float* planes, uint32_t n_planes, const float* spheres,
+                            uint32_t n_spheres, mc_pathtrace_kernel_info* out);
 int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
                      const float* spheres, uint32_t n_spheres, void* d_rgba, hipStream_t s);
 // postprocess.hip

@@ -241,6 +241,7 @@ static int multi_pathtrace(mc_multi* m, const mc_pathtrace_params* p, const floa
     for (int i = 0; i < m->n; i++) {
         MC_HIP_TRY(hipSetDevice(m->ctx[i]->device));
         MC_HIP_TRY(hipStreamSynchronize(m->ctx[i]->stream));
+        if ((rc = m->ctx[i]->check_status())) return rc;   // a pool kernel's tripped scheduling bound: never a silent partial image
     }
     return MC_OK;
 }

@@ -117,28 +117,83 @@ static bool spheres_disjoint(const float* spheres) {
     return true;
 }
 
+// A light (all but) ENCLOSED by an opaque sphere — found by tools/fuzz_fast.py: 0.01 of a light poking out of a diffuse sphere — is seen
+// only through grazing decisions between the two surfaces, each worth a firefly of the light's full emission: which of the two roots
+// is nearer decides the sample, and the fast kernels' contracted arithmetic decides 2-4 % of the pixels the other way (RMSE 3.6 / p99.9 77
+// against the 0.5 / 4 bound at 300x200x256) while the oracle's own two evaluations stay inside it (0.17 / 0.48).  Fast math cannot hold
+// its tolerance there, so it does not run there: the host classifies the scene (mc_pathtrace_scene_class bit 3) and renders an
+// MC_PT_MATH_FAST request with the strict kernels.  Criterion: an emissive sphere i whose outermost point lies less than
+// kEnclosedMargin * r_i outside a non-emissive opaque (material 1 / 2) sphere j, or inside it: |c_i - c_j| + r_i - r_j < margin * r_i.
+// (A light inside a GLASS sphere is well conditioned — next-event estimation never passes the glass, :420 — and two lights inside each
+// other both emit.)  Calibration of the margin: tools/enclosed_light_sweep.py, profiles/r04_enclosed_light_sweep.txt.
+constexpr double kEnclosedMargin = 1.0;
+bool light_nearly_enclosed(const float* spheres, uint32_t n_spheres) {
+    for (uint32_t i = 0; i < n_spheres; i++) {
+        const float* si = spheres + 12 * i;
+        if (!(h_dot(v3{si[4], si[5], si[6]}, v3{si[4], si[5], si[6]}) > 0.0f)) continue;   // :407
+        for (uint32_t j = 0; j < n_spheres; j++) {
+            const float* sj = spheres + 12 * j;
+            if (j == i || h_dot(v3{sj[4], sj[5], sj[6]}, v3{sj[4], sj[5], sj[6]}) > 0.0f) continue;
+            if (floorf(sj[11] + 0.5f) == 3.0f) continue;                                    // glass
+            const double dx = (double)si[0] - sj[0], dy = (double)si[1] - sj[1], dz = (double)si[2] - sj[2];
+            const double ri = std::fabs((double)si[3]), rj = std::fabs((double)sj[3]);
+            const double out = std::sqrt(dx * dx + dy * dy + dz * dz) + ri - rj;           // how far the light pokes out of sphere j
+            if (!(out >= kEnclosedMargin * ri)) return true;                                // (also NaN)
+        }
+    }
+    return false;
+}
+
 // Host-side scene analysis behind mc_pathtrace_scene_class (no device involved): bit 0 = the scene takes the slab
-// kernels, bit 1 = its shadow rays skip the plane tests, bit 2 = its three spheres are pairwise disjoint.
+// kernels, bit 1 = its shadow rays skip the plane tests, bit 2 = its three spheres are pairwise disjoint, bit 3 = a light is
+// (all but) enclosed by an opaque sphere (any scene: fast math is then rendered by the strict kernels).
 uint32_t pathtrace_scene_class(const float* planes, uint32_t n_planes, const float* spheres, uint32_t n_spheres) {
     PTArgs a;
     std::memset(&a, 0, sizeof(a));
     set_camera(a);
-    if (!analyse_slabs(planes, n_planes, n_spheres, a.scene)) return 0u;
-    return 1u | (lights_inside_box(a.scene, spheres, n_spheres, a.cam_o, a.lc) ? 2u : 0u) | (spheres_disjoint(spheres) ? 4u : 0u);
+    const uint32_t ill = light_nearly_enclosed(spheres, n_spheres) ? MC_PT_SCENE_LIGHT_ENCLOSED : 0u;
+    if (!analyse_slabs(planes, n_planes, n_spheres, a.scene)) return ill;
+    return 1u | (lights_inside_box(a.scene, spheres, n_spheres, a.cam_o, a.lc) ? 2u : 0u) | (spheres_disjoint(spheres) ? 4u : 0u) | ill;
 }
 
-int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
-                     const float* spheres, uint32_t n_spheres, void* d_rgba, hipStream_t s) {
-    if (!ctx || !p || !d_rgba || (!planes && n_planes) || (!spheres && n_spheres)) return MC_ERR_INVALID_ARGUMENT;
+namespace {
+
+// What pathtrace_launch will run for a request: decided on the host from the parameters and the scene alone (no device state), so
+// that mc_pathtrace_select_kernel can tell a caller — an N-GPU or progressive one wants the SAME kernel for every tile and range.
+struct PTPlan {
+    int variant = 0;          // MC_PT_KERNEL_*: 0 generic (scene staged in LDS), 1 slab, 3 closed box, 4 sample pool, 5 generic (scene in memory)
+    int S = 1;                // sample-parallel width of the (first) launch
+    int tail_S = 0;           // round-synchronous kernels, ragged sample count: width of the second launch (0: one launch)
+    int prec = 0;
+    bool slab = false;
+    uint32_t math_mode = MC_PT_MATH_STRICT;   // the mode that RUNS (a fast request may be rendered strict: light_nearly_enclosed)
+    uint32_t n_emissive = 0;  // generic scenes
+};
+
+// Validates the request, fills `a` (everything but the generic scenes' device pointers) and chooses the kernel.
+int pathtrace_plan(const mc_pathtrace_params* p, const float* planes, uint32_t n_planes, const float* spheres, uint32_t n_spheres,
+                   PTArgs& a, PTPlan& plan) {
+    if (!p || (!planes && n_planes) || (!spheres && n_spheres)) return MC_ERR_INVALID_ARGUMENT;
     if (!p->width || !p->height || !p->spp || p->row_end > p->height || p->row_begin >= p->row_end ||
         p->sample_end > p->spp || p->sample_begin >= p->sample_end)   // an empty range would re-apply the epilogue (:453)
         return MC_ERR_INVALID_ARGUMENT;
     if (p->math_mode != MC_PT_MATH_STRICT && p->math_mode != MC_PT_MATH_FAST) return MC_ERR_INVALID_ARGUMENT;
     if (p->row_stride && (!p->row_block || p->row_block > p->row_stride)) return MC_ERR_INVALID_ARGUMENT;
+    // flags: bits 0, 2-6 diagnostics, bits 8-15 MC_PT_FORCE_S, bits 16-19 MC_PT_PRECISION; everything else is reserved (bit 1 was the
+    // removed lane-regrouping experiment) and refused, so that a stray bit never selects a kernel silently
+    constexpr uint32_t kKnownFlags = MC_PT_GENERIC_KERNEL | MC_PT_NO_BOX_KERNEL | MC_PT_NO_POOL_KERNEL | MC_PT_SCENE_IN_LDS |
+                                     MC_PT_SCENE_IN_MEMORY | MC_PT_NO_FAST_GUARD | 0xff00u | 0xf0000u;
+    if (p->flags & ~kKnownFlags) {
+        set_error_detail("mc_pathtrace_params.flags: reserved bits set");
+        return MC_ERR_INVALID_ARGUMENT;
+    }
+    const int prec = (int)((p->flags >> 16) & 0xfu);   // MC_PT_PRECISION(x)
+    if (prec > 3) return MC_ERR_INVALID_ARGUMENT;
+    plan.prec = prec;
     // A scene beyond the LDS-resident store (about 3000 objects) is read from memory — by the fp32 kernels; the extended-precision
     // sphere branches exist for LDS-resident scenes only, as does the forced MC_PT_SCENE_IN_LDS.
     const bool beyond_lds = ((size_t)n_planes + n_spheres) * 48u + (size_t)n_spheres * 4u > pt::kMaxSceneLdsBytes;
-    if (beyond_lds && ((((p->flags >> 16) & 0xffu) != 0u) || (p->flags & MC_PT_SCENE_IN_LDS))) {
+    if (beyond_lds && (prec != 0 || (p->flags & MC_PT_SCENE_IN_LDS))) {
         set_error_detail("scene exceeds the LDS-resident scene store (about 3000 objects): fp32 sphere test from memory only");
         return MC_ERR_UNSUPPORTED;
     }
@@ -146,7 +201,11 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
         set_error_detail("more than 2^20 objects");
         return MC_ERR_UNSUPPORTED;
     }
-    PTArgs a;
+    // Fast math never runs where it cannot hold its tolerance (light_nearly_enclosed): such a request is rendered strict.
+    plan.math_mode = p->math_mode;
+    if (p->math_mode == MC_PT_MATH_FAST && !(p->flags & MC_PT_NO_FAST_GUARD) && light_nearly_enclosed(spheres, n_spheres))
+        plan.math_mode = MC_PT_MATH_STRICT;
+    const bool fast = plan.math_mode == MC_PT_MATH_FAST;
     std::memset(&a, 0, sizeof(a));
     a.W = p->width; a.H = p->height; a.spp = p->spp;
     a.sample_begin = p->sample_begin; a.sample_end = p->sample_end;
@@ -154,11 +213,9 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
     a.row_block = p->row_stride ? p->row_block : 0u; a.row_stride = p->row_stride;
     set_camera(a);
     a.inv_W = 1.0f / (float)p->width; a.inv_H = 1.0f / (float)p->height; a.inv_spp = 1.0f / (float)p->spp;
-    a.out = (float4*)d_rgba;
     a.scene.n_planes = n_planes; a.scene.n_spheres = n_spheres;
-    const int prec = (int)((p->flags >> 16) & 0xfu);   // MC_PT_PRECISION(x)
-    if (prec > 3) return MC_ERR_INVALID_ARGUMENT;
     const bool slab = prec == 0 && analyse_slabs(planes, n_planes, n_spheres, a.scene) && !(p->flags & MC_PT_GENERIC_KERNEL);
+    plan.slab = slab;
     if (slab) {   // 6 planes + 3 spheres: the records travel in the kernel-argument segment, planes in canonical
                   // slab order (x-,x+,y-,y+,z-,z+) so that the kernel's plane id is 2*axis + (d[axis] > 0)
         for (int ax = 0; ax < 3; ax++) {
@@ -198,8 +255,85 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
         a.scene.spheres_disjoint = spheres_disjoint(spheres) ? 1u : 0u;
         // closed-box fast kernel: no ray may ever leave the box (pathtrace_kernel.h, intersect_box)
         a.scene.box_ok = (a.scene.nee_skip_planes && a.scene.materials_known && !glass_wall && a.scene.emit_skip_ok) ? 1u : 0u;
-    } else {      // any other scene: device buffer [records | emissive sphere indices | records with the derived slots], staged
-                  // into LDS by the kernel — or, for large scenes, read where they lie (the third part)
+    } else {
+        for (uint32_t i = 0; i < n_spheres; i++) {
+            const float* sp = spheres + 12 * i;
+            if (h_dot(v3{sp[4], sp[5], sp[6]}, v3{sp[4], sp[5], sp[6]}) > 0.0f) plan.n_emissive++;   // pathTracer.comp:407
+        }
+    }
+    const uint32_t rows = tile_rows(p->row_begin, p->row_end, a.row_block, a.row_stride);
+    int S = (int)((p->flags >> 8) & 0xffu);   // MC_PT_FORCE_S(s)
+    const bool auto_width = S == 0;
+    if (S == 0) S = choose_S((uint64_t)rows * p->width, p->sample_end - p->sample_begin);
+    if (S != 1 && S != 4 && S != 16) return MC_ERR_INVALID_ARGUMENT;
+    if (prec != 0 && S == 4) S = (p->sample_end - p->sample_begin) >= 16 ? 16 : 1;   // precision variants exist for S = 1, 16
+    int variant = slab ? 1 : 0;
+    // Generic scenes (fp32 sphere test): the records are staged into LDS by every block while that leaves room for a full set of
+    // blocks per CU, else read from memory (MC_PT_SCENE_IN_LDS / MC_PT_SCENE_IN_MEMORY force one or the other; same results)
+    if (!slab && prec == 0) {
+        const size_t lds = ((size_t)(n_planes + n_spheres) * 12u + plan.n_emissive) * sizeof(float);
+        bool in_memory = lds > pt::kSceneLdsAutoBytes;
+        if (p->flags & MC_PT_SCENE_IN_LDS) in_memory = false;
+        if (p->flags & MC_PT_SCENE_IN_MEMORY) in_memory = true;
+        if (in_memory) variant = 5;
+    }
+    if (slab && a.scene.box_ok && !(p->flags & MC_PT_NO_BOX_KERNEL)) {
+        if (fast) variant = 3;   // the closed-box round-synchronous kernels (scene facts at compile time)
+        // The sample-pool kernels (pathtrace_pool.h): fast math whole sample ranges only (the pixel sums are formed inside the launch), the
+        // automatic width; 16 lanes per pixel and batch (2 x 2 pixels per wave) for every image size — never a function of the tile.
+        // Fast math adds a pixel's radiance in an order that depends on the wave's schedule, so it is selected only for tiles whose
+        // wave tiles are those of the whole image — a wave's pixels, hence its schedule, are then the same for every tiling:
+        // N-GPU output == 1-GPU output, bit for bit.  The strict variant adds in sample order whatever the tile.
+        const uint32_t th = 2u;   // WaveTile<16>::h
+        // (strict: any sample range — the ordered sum continues from the stored accumulator exactly as the round-synchronous kernels'
+        // does; fast: whole ranges only, its per-lane partial sums would make a progressive render differ from a one-launch one)
+        const bool whole_range = !fast || (p->sample_begin == 0u && p->sample_end == p->spp);
+        const bool aligned = p->row_begin % th == 0u && (a.row_block == 0u || (a.row_block % th == 0u && a.row_stride % th == 0u)) &&
+                             (p->row_end % th == 0u || p->row_end == p->height);
+        const bool fits = p->max_depth >= 1u && (uint64_t)p->spp * p->max_depth < (1ull << 32) && p->width < (1u << 24);
+        // (the fast pool kernel orders a shadow ray's spheres by their centres' projections: disjoint spheres only)
+        if (auto_width && !(p->flags & MC_PT_NO_POOL_KERNEL) && whole_range && (aligned || !fast) && fits &&
+            (!fast || a.scene.spheres_disjoint))
+            variant = 4;
+    }
+    plan.variant = variant;
+    plan.S = variant == 4 ? 16 : S;
+    // Ragged sample count (K2: 500 = 31 x 16 + 4) in the round-synchronous kernels: the last round of the S-wide kernel would run
+    // with S - r of every S lanes idle.  Render the full rounds, then the r remaining samples as a progressive continuation (the same
+    // mechanism a caller uses through sample_begin/sample_end: the fp32 accumulator round-trips through the storage buffer
+    // unchanged, so the sum — and its order — is the same) with a narrower sample-parallel width.  (The pool kernels handle it inside.)
+    const uint32_t n_samples = p->sample_end - p->sample_begin;
+    const uint32_t rest = n_samples % (uint32_t)S;
+    if (variant != 4 && auto_width && prec == 0 && S > 1 && rest != 0u && n_samples > (uint32_t)S) plan.tail_S = rest >= 4u ? 4 : 1;
+    return MC_OK;
+}
+
+}  // namespace
+
+int pathtrace_select_kernel(const mc_pathtrace_params* p, const float* planes, uint32_t n_planes, const float* spheres,
+                            uint32_t n_spheres, mc_pathtrace_kernel_info* out) {
+    if (!out) return MC_ERR_INVALID_ARGUMENT;
+    PTArgs a;
+    PTPlan plan;
+    int rc = pathtrace_plan(p, planes, n_planes, spheres, n_spheres, a, plan);
+    if (rc) return rc;
+    out->kernel = (uint32_t)plan.variant;
+    out->lanes_per_pixel = (uint32_t)plan.S;
+    out->math_mode = plan.math_mode;
+    out->launches = plan.tail_S ? 2u : 1u;
+    return MC_OK;
+}
+
+int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
+                     const float* spheres, uint32_t n_spheres, void* d_rgba, hipStream_t s) {
+    if (!ctx || !d_rgba) return MC_ERR_INVALID_ARGUMENT;
+    PTArgs a;
+    PTPlan plan;
+    int rc = pathtrace_plan(p, planes, n_planes, spheres, n_spheres, a, plan);
+    if (rc) return rc;
+    a.out = (float4*)d_rgba;
+    if (!plan.slab) {   // any other scene: device buffer [records | emissive sphere indices | records with the derived slots], staged
+                        // into LDS by the kernel — or, for large scenes, read where they lie (the third part)
         const size_t n_rec = (size_t)(n_planes + n_spheres) * 12;
         std::vector<float> host(n_rec + n_spheres);
         if (n_planes) std::memcpy(host.data(), planes, sizeof(float) * 12 * n_planes);
@@ -224,7 +358,7 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
         if (host != ctx->scene_host || !ctx->scene_buf.ptr) {            // upload only when the scene changed
             // Earlier launches of THIS context may still read the old copy: wait for the streams it has launched on
             // (never the whole device — other contexts and streams keep running), then upload in stream order.
-            int rc = ctx->drain_launch_streams();
+            rc = ctx->drain_launch_streams();
             if (rc) return rc;
             if ((rc = ctx->scene_buf.reserve(host.size() * sizeof(float) + 16))) return rc;
             ctx->scene_host.clear();   // the cache key is only valid once the upload has succeeded
@@ -238,88 +372,29 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
         a.scene.n_emissive = n_em;
     }
     const uint32_t rows = tile_rows(p->row_begin, p->row_end, a.row_block, a.row_stride);
-    int S = (int)((p->flags >> 8) & 0xffu);   // MC_PT_FORCE_S(s)
-    if (S == 0) S = choose_S((uint64_t)rows * p->width, p->sample_end - p->sample_begin);
-    if (S != 1 && S != 4 && S != 16) return MC_ERR_INVALID_ARGUMENT;
-    if (prec != 0 && S == 4) S = (p->sample_end - p->sample_begin) >= 16 ? 16 : 1;   // precision variants exist for S = 1, 16
-    int variant = slab ? 1 : 0;
-    // Generic scenes (fp32 sphere test): the records are staged into LDS by every block while that leaves room for a full set of
-    // blocks per CU, else read from memory (MC_PT_SCENE_IN_LDS / MC_PT_SCENE_IN_MEMORY force one or the other; same results)
-    if (!slab && prec == 0) {
-        const size_t lds = ((size_t)(n_planes + n_spheres) * 12u + a.scene.n_emissive) * sizeof(float);
-        bool in_memory = lds > pt::kSceneLdsAutoBytes;
-        if (p->flags & MC_PT_SCENE_IN_LDS) in_memory = false;
-        if (p->flags & MC_PT_SCENE_IN_MEMORY) in_memory = true;
-        if (in_memory) variant = 5;
-    }
-    if (slab && a.scene.box_ok && !(p->flags & MC_PT_NO_BOX_KERNEL)) {
-        const bool fast = p->math_mode == MC_PT_MATH_FAST;
-        if (fast) variant = 3;   // the closed-box round-synchronous kernels (scene facts at compile time)
-        // The sample-pool kernels (pathtrace_pool.h): fast math whole sample ranges only (the pixel sums are formed inside the launch), the
-        // automatic width; 16 lanes per pixel and batch (2 x 2 pixels per wave) for every image size — never a function of the tile.
-        // Fast math adds a pixel's radiance in an order that depends on the wave's schedule, so it is selected only for tiles whose
-        // wave tiles are those of the whole image — a wave's pixels, hence its schedule, are then the same for every tiling:
-        // N-GPU output == 1-GPU output, bit for bit.  The strict variant adds in sample order whatever the tile.
-        const uint32_t th = 2u;   // WaveTile<16>::h
-        // (strict: any sample range — the ordered sum continues from the stored accumulator exactly as the round-synchronous kernels'
-        // does; fast: whole ranges only, its per-lane partial sums would make a progressive render differ from a one-launch one)
-        const bool whole_range = !fast || (p->sample_begin == 0u && p->sample_end == p->spp);
-        const bool aligned = p->row_begin % th == 0u && (a.row_block == 0u || (a.row_block % th == 0u && a.row_stride % th == 0u)) &&
-                             (p->row_end % th == 0u || p->row_end == p->height);
-        const bool fits = p->max_depth >= 1u && (uint64_t)p->spp * p->max_depth < (1ull << 32) && p->width < (1u << 24);
-        // (the fast pool kernel orders a shadow ray's spheres by their centres' projections: disjoint spheres only)
-        if (((p->flags >> 8) & 0xffu) == 0u && !(p->flags & MC_PT_NO_POOL_KERNEL) && whole_range && (aligned || !fast) && fits &&
-            (!fast || a.scene.spheres_disjoint))
-            variant = 4;
-    }
-    // Lane-regrouping scheduler (pathtrace_regroup.h): slab scenes whose materials are all 1..3 (any other code makes the
-    // shader re-trace an unchanged ray, which only the round-synchronous loop reproduces) within its packed-field limits.
-    bool regroup_ok = slab && prec == 0 && p->max_depth <= 63u && p->width < 65536u && p->height <= 65536u &&
-                      (p->sample_end - p->sample_begin) < (1u << 20);
-    regroup_ok = regroup_ok && a.scene.materials_known != 0u;
-    // Never the default: measured slower than the round-synchronous kernels.  The kernel is compiled only
-    // into the diagnostic library (make regroup, -DMC_PT_WITH_REGROUP); the shipped library answers MC_ERR_UNSUPPORTED.
-    if (p->flags & MC_PT_KERNEL_REGROUP) {
-#ifdef MC_PT_WITH_REGROUP
-        if (regroup_ok) variant = 2;   // outside its limits the request falls back to the round-synchronous kernels
-#else
-        (void)regroup_ok;
-        set_error_detail("MC_PT_KERNEL_REGROUP: the lane-regrouping kernel is only built into lib/libmc_compute_regroup.so (make regroup)");
-        return MC_ERR_UNSUPPORTED;
-#endif
-    }
-    if (variant == 2) {
-        int rc = ctx->ensure_status();
+    // The sample-pool kernels bound their scheduling loop; a tripped bound (a scheduling defect, never seen) sets a bit of the
+    // context's status word instead of storing an incomplete image silently: the blocking entry points and
+    // mc_context_synchronize() then return MC_ERR_HIP.
+    if (plan.variant == 4) {
+        rc = ctx->ensure_status();
         if (rc) return rc;
         a.status = (uint32_t*)ctx->status.ptr;
     }
     auto launch = [&](const PTArgs& args, int width) {
-        return p->math_mode == MC_PT_MATH_FAST ? pt::launch_fast(args, variant, width, prec, rows, s)
-                                               : pt::launch_strict(args, variant, width, prec, rows, s);
+        return plan.math_mode == MC_PT_MATH_FAST ? pt::launch_fast(args, plan.variant, width, plan.prec, rows, s)
+                                                 : pt::launch_strict(args, plan.variant, width, plan.prec, rows, s);
     };
-    // Ragged sample count (K2: 500 = 31 x 16 + 4): the last round of the S-wide kernel would run with S - r of every S
-    // lanes idle.  Render the full rounds, then the r remaining samples as a progressive continuation (the same
-    // mechanism a caller uses through sample_begin/sample_end: the fp32 accumulator round-trips through the storage
-    // buffer unchanged, so the sum — and its order — is the same) with a narrower sample-parallel width.
-    const uint32_t n_samples = p->sample_end - p->sample_begin;
-    const bool auto_width = ((p->flags >> 8) & 0xffu) == 0u;
-    const uint32_t rest = n_samples % (uint32_t)S;
-    if (variant == 2 || variant == 4) {
-        int rc = launch(a, 16);   // (regroup: S ignored; pool: 16 lanes per pixel, ragged sample counts handled inside)
-        if (rc) return rc;
-    } else if (auto_width && prec == 0 && S > 1 && rest != 0u && n_samples > (uint32_t)S) {
+    if (plan.tail_S) {
+        const uint32_t rest = (p->sample_end - p->sample_begin) % (uint32_t)plan.S;
         PTArgs head = a, tail = a;
         head.sample_end = tail.sample_begin = a.sample_end - rest;
-        int rc = launch(head, S);
-        if (rc) return rc;
-        rc = launch(tail, rest >= 4u ? 4 : 1);
-        if (rc) return rc;
+        if ((rc = launch(head, plan.S))) return rc;
+        if ((rc = launch(tail, plan.tail_S))) return rc;
     } else {
-        int rc = launch(a, S);
-        if (rc) return rc;
+        if ((rc = launch(a, plan.S))) return rc;
     }
     MC_HIP_TRY(hipGetLastError());
-    return slab ? MC_OK : ctx->note_launch(s);   // only the generic kernels read a cached device table
+    return plan.slab ? MC_OK : ctx->note_launch(s);   // only the generic kernels read a cached device table
 }
 
 }  // namespace mc

@@ -24,17 +24,10 @@
 #endif
 #include "pathtrace_kernel.h"
 #include "pathtrace_pool.h"
-#ifdef MC_PT_WITH_REGROUP   // diagnostic library only (make regroup): the lane-regrouping scheduler, DESIGN.md §3.3
-#include "pathtrace_regroup.h"
-#endif
 
 namespace mc {
 namespace pt {
 int launch_fast(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s) {
-#ifdef MC_PT_WITH_REGROUP
-    if (variant == 2) return launch_regroup<true, 4>(a, tile_rows, s);
-#endif
-    if (variant == 2) return MC_ERR_UNSUPPORTED;
     if (variant == 4) return launch_pool<true>(a, S, tile_rows, s);
     return launch_impl<true>(a, variant, S, prec, tile_rows, s);
 }

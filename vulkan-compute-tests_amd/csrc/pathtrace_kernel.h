@@ -1101,7 +1101,7 @@ __global__ void __launch_bounds__(256, Fast ? 6 : 5) pathtrace_kernel(PTArgs a) 
 // variant: 0 = generic (run-time object counts), 1 = slab-specialised 6 planes + 3 spheres.
 // prec: 0 = fp32 sphere test (the reference's default build); 1/2/3 = native fp64 / DS / DF64 branch (generic kernel,
 // S in {1,16} only).
-// variant 2 = the lane-regrouping scheduler (pathtrace_regroup.h; slab scenes, S is ignored; diagnostic library only).
+// variant 4 = the sample-pool kernels (pathtrace_pool.h; closed-box slab scenes), variant 5 = generic, scene read from memory.
 // variant 3 = the closed-box fast kernel (slab scenes with SceneArgs::box_ok, fast math only).
 int launch_fast(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s);
 int launch_strict(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s);

@@ -152,7 +152,11 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
     float rx = 0.0f, ry = 0.0f;
     bool alive = false;
     // every iteration either traces a bounce of a live lane, or consumes stash entries, or produces a batch: bounded
-    const unsigned long long max_iters = (unsigned long long)n_batches * S * (a.max_depth + 2ull) + 64ull;
+    unsigned long long max_iters = (unsigned long long)n_batches * S * (a.max_depth + 2ull) + 64ull;
+#ifdef MC_PT_POOL_TEST_BOUND   // diagnostic build only (tests/test_gpu_pool.py): a bound the loop must trip
+    max_iters = MC_PT_POOL_TEST_BOUND;
+#endif
+    bool finished = false;
     for (unsigned long long it = 0; it < max_iters; it++) {
         // ---- lanes whose path ended take their pixel's next camera rays
         // (MC_REGION: diagnostic build only — make stats, tools/pool_region_stats.py — executions and active lanes per block)
@@ -230,7 +234,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
             ghead += need < avail ? need : avail;
         }
         // pool exhausted and every path ended?  (no lane alive but entries left: only empty entries were taken — go round again)
-        if (__ballot(alive) == 0ull && batch >= n_batches && __ballot(ghead != batch * (uint32_t)S) == 0ull) break;
+        if (__ballot(alive) == 0ull && batch >= n_batches && __ballot(ghead != batch * (uint32_t)S) == 0ull) { finished = true; break; }
         // ---- one bounce of every live lane: prologue, material, intersection of the next depth (the rotated loop of trace_sample)
         // (structured ifs, no break / continue: every extra exit edge of this block cost a dozen register copies at its merge)
         if (alive) {
@@ -345,6 +349,8 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
             }
         }
     }
+    // the bound tripped (a scheduling defect): say so — the image is incomplete (mc_context::check_status -> MC_ERR_HIP)
+    if (!finished && a.status && (threadIdx.x & 63u) == 0u) atomicOr(a.status, 2u);
     float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const Lane fin = my_lane(true);
     if constexpr (Fast) {

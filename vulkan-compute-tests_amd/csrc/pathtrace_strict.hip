@@ -2,17 +2,10 @@
 // bit-identical to the CPU oracle).  Split from the fast instantiations so both compile in parallel.
 #include "pathtrace_kernel.h"
 #include "pathtrace_pool.h"
-#ifdef MC_PT_WITH_REGROUP   // diagnostic library only (make regroup)
-#include "pathtrace_regroup.h"
-#endif
 
 namespace mc {
 namespace pt {
 int launch_strict(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s) {
-#ifdef MC_PT_WITH_REGROUP
-    if (variant == 2) return launch_regroup<false, 4>(a, tile_rows, s);
-#endif
-    if (variant == 2) return MC_ERR_UNSUPPORTED;
     if (variant == 4) return launch_pool<false>(a, S, tile_rows, s);
     return launch_impl<false>(a, variant, S, prec, tile_rows, s);
 }

@@ -1,6 +1,5 @@
 #include "computeApp.h"
 
-#include "pngReference.h"
 #include "pngWriter.h"
 
 #include <chrono>
@@ -49,9 +48,5 @@ void ComputeApp::run() {
 }
 
 std::string ComputeApp::writePng(const char* filename, const uint8_t* rgba8, uint32_t w, uint32_t h) const {
-    if (!fastPng) {
-        const std::string err = pngref::encodeFile(filename, rgba8, w, h);
-        if (err != "alpha") return err;   // ("alpha": not an opaque image — outside the reference-compatible encoder's contract)
-    }
     return pngwriter::encodeFile(filename, rgba8, w, h, pngThreads);
 }

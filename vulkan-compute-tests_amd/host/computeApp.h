@@ -42,10 +42,10 @@ struct ComputeApp {
     // not copied to the host (storageBuffer() stays empty).  Same cast semantics, same bytes.
     void setGpuPostprocess(bool g) { gpuPostprocess = g; }
     void setPngThreads(int t) { pngThreads = t; }   // 0 = all cores, 1 = serial deflate
-    void setFastPng(bool f) { fastPng = f; }         // true: the parallel writer (same pixels, its own deflate stream)
-    // saveRenderedImage's file: by default the bytes the reference's codec writes for these pixels (pngReference.h:
-    // mandelbrotApp.h:181 / pathtracerApp.h:245 call lodepng::encode at its defaults); --fast-png, or an image that is not
-    // opaque, takes the parallel writer of pngWriter.h.
+    // saveRenderedImage's file: a standard PNG of exactly the RGBA8 pixels the reference converts its buffer to (mandelbrotApp.h:159-174,
+    // pathtracerApp.h:202-243), deflated stripe-parallel by pngWriter.h.  The reference encodes the same pixels with its vendored
+    // third-party codec (lodepng::encode, mandelbrotApp.h:181 / pathtracerApp.h:245): a reference tree that calls this library
+    // (INTEGRATION.md route B) keeps that call and therefore its exact bytes; the standalone apps do not re-implement that codec.
     std::string writePng(const char* filename, const uint8_t* rgba8, uint32_t w, uint32_t h) const;
     double lastRunMilliseconds() const { return lastRunMs; }
 
@@ -60,7 +60,6 @@ protected:
     bool quiet = false;
     bool gpuPostprocess = false;
     int pngThreads = 0;
-    bool fastPng = false;
     std::vector<uint8_t> rgba8;   // filled by run() when gpuPostprocess is on
     double lastRunMs = 0.0;
     // The storage buffer, host side: vec4 fp32 per pixel, row-major (what vkMapMemory exposes to

@@ -3,7 +3,6 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "pngReference.h"
 #include "pngWriter.h"
 
 extern "C" {
@@ -20,16 +19,6 @@ int mcu_png_encode_mt(const uint8_t* rgba8, uint32_t w, uint32_t h, int threads,
 }
 int mcu_png_encode(const uint8_t* rgba8, uint32_t w, uint32_t h, uint8_t** out, size_t* out_len) {
     return mcu_png_encode_mt(rgba8, w, h, 0, out, out_len);
-}
-// The reference-compatible encoder (pngReference.h): 0 = ok, 1 = not opaque / empty, 2 = out of memory.
-int mcu_png_encode_reference(const uint8_t* rgba8, uint32_t w, uint32_t h, uint8_t** out, size_t* out_len) {
-    std::vector<uint8_t> png;
-    if (!pngref::encode(png, rgba8, w, h).empty()) return 1;
-    *out = (uint8_t*)std::malloc(png.size());
-    if (!*out) return 2;
-    std::memcpy(*out, png.data(), png.size());
-    *out_len = png.size();
-    return 0;
 }
 void mcu_free(void* p) { std::free(p); }
 

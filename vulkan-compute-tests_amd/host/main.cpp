@@ -31,7 +31,6 @@ int main(int argc, char* argv[]) {
     int gpus = 1;
     bool quiet = false, gpuPost = false;
     int pngThreads = 0;
-    bool fastPng = false;
     const char* outFile = nullptr;
     uint32_t width = 2000, height = 2000, maxIter = 128, precision = MC_PRECISION_F32, mathMode = MC_PT_MATH_STRICT;
     double cx = -0.445, cy = 0.0, sx = 2.34, sy = 2.34;
@@ -45,7 +44,7 @@ int main(int argc, char* argv[]) {
         else if (a == "--quiet") quiet = true;
         else if (a == "--gpu-postprocess") gpuPost = true;     // float->u8 (+rotation) on the device, RGBA8-only download
         else if (a == "--png-threads") { need(1); pngThreads = atoi(argv[++i]); }   // 0 = all cores (default), 1 = serial
-        else if (a == "--fast-png") fastPng = true;            // parallel deflate instead of the reference codec's byte stream
+        else if (a == "--fast-png") {}                         // (accepted for round-3 command lines: the parallel writer is the only one)
         else if (a == "--width") { need(1); width = (uint32_t)atoi(argv[++i]); }
         else if (a == "--height") { need(1); height = (uint32_t)atoi(argv[++i]); }
         else if (a == "--max-iter") { need(1); maxIter = (uint32_t)atoi(argv[++i]); }
@@ -80,7 +79,6 @@ int main(int argc, char* argv[]) {
     app.setQuiet(quiet);
     app.setGpuPostprocess(gpuPost);
     app.setPngThreads(pngThreads);
-    app.setFastPng(fastPng);
 
     try {
         // the reference calls init()/preRun() outside its try block (main.cpp:28-29); a missing device
