@@ -57,7 +57,7 @@ WORKLOAD_ALIAS = {"pathtrace": "K2", "mandelbrot": "K1", "mandelbrot_ds": "K1ds"
 PROFILE_TAG = {"K2": {"fast": "pt_fast", "strict": "pt_strict"}, "K1": "mandel", "K1ds": "mandel_ds"}
 
 
-PROFILE_ROUNDS = ("r03", "r02", "r01d", "r01c")
+PROFILE_ROUNDS = ("r04", "r03", "r02", "r01d", "r01c")
 
 
 def profiled_summary(cfg_name, args, n):
@@ -362,14 +362,27 @@ def main():
     out = None
     if rank == 0:
         achieved_tflops = local_units * flops_per_unit / (kernel_ms * 1e-3) / 1e12
-        kern = "pathtrace_kernel" if is_pt else ("mandelbrot_kernel<StateDS>" if cfg["ds"] else "mandelbrot_kernel<StateF32>")
+        if is_pt:   # the kernel the host selected for this request (mc_pathtrace_select_kernel: the same decision the launch made)
+            ki = B.pathtrace_select_kernel(p)
+            fast_ran = ki.math_mode == B.PT_MATH_FAST
+            kern = (f"pathtrace_pool_kernel<{'true' if fast_ran else 'false'}, {ki.lanes_per_pixel}, 3>" if ki.kernel == B.PT_KERNEL_POOL
+                    else f"pathtrace_kernel<{B.PT_KERNEL_NAMES[ki.kernel]}, fast={str(fast_ran).lower()}, S={ki.lanes_per_pixel}>")
+        else:
+            kern = "mandelbrot_kernel<StateDS>" if cfg["ds"] else "mandelbrot_kernel<StateF32>"
         traffic, traffic_source = profiled_traffic(cfg_name, args, n)
         exec_flops, exec_source = profiled_executed_lane_flops(cfg_name, args, n)
         # the algorithmic bytes are the 16-B storage-buffer entry per pixel, written ONCE (the Mandelbrot kernel
         # also writes its 4-B iteration count, the parity object).  More launches per step or an accumulator re-read show up
         # in `traffic` (PMC) and in `traffic_ratio`, not here.
         alg_bytes = W * rows_local * (16 if is_pt else 20)
-        peak_at_clock = cus * 4 * 32 * sclk_mhz * 1e6          # lane-ops/s at the clock this box held under VALU load
+        # The clock the kernel itself held, from the committed PMC pass of this configuration (GRBM_GUI_ACTIVE / 8 XCDs / duration).
+        # NOT mc_context_measure_clock: that probe reads the clock under ITS OWN dense FMA chain — 2.15 GHz after a K3 step during
+        # which the path tracer held 2.38 GHz (profiles/r04_k3_clock.txt) — and is kept only to compare boxes.
+        prof_entries, _ = profiled_summary(cfg_name, args, n)
+        prof_ghz = None
+        for e in (prof_entries or {}).values():
+            prof_ghz = e.get("derived", {}).get("kernel_clock_ghz") or prof_ghz
+        contracted = is_pt and args.math == "fast"
         if is_pt and args.math == "fast":
             note = ("fast math: hardware transcendentals, a*b+c contraction, identities of exact arithmetic not executed (toleranced "
                     "parity); `achieved` counts the REFERENCE's arithmetic per sample, `executed` what the ALUs did; the strict "
@@ -394,7 +407,9 @@ def main():
                                        ("; synchronous gather on the render stream" if ex.sync_mode or backend != "nccl" else
                                         "; asynchronous gather + re-assembly on a side stream, overlapping the next step's render")}
                           if n > 1 else {}),
-                       "device": dev_name, "compute_units": cus, "sclk_mhz_under_valu_load": round(sclk_mhz, 1),
+                       **({"exchange_async": bool(not ex.sync_mode and backend == "nccl")} if n > 1 else {}),
+                       "device": dev_name, "compute_units": cus, "sclk_mhz_probe_kernel": round(sclk_mhz, 1),
+                       "sclk_note": "clock under the PROBE kernel's dense FMA chain (compares boxes); the timed kernel's own clock is roofline.kernel_clock_ghz_profiled",
                        **({"unit_note": "reference-equivalent pixel-iterations (see roofline.lane_ops.note)"} if not is_pt else {}),
                        **({"backend": backend, "world_size": dist.get_world_size(), "ranks": ranks_info,
                            "gather_ms_rank0": round(gather_ms, 4), "gather_bytes_per_rank": gather_bytes,
@@ -405,8 +420,8 @@ def main():
                        **({"verified_equal_to_single_gpu": verified} if verified is not None else {})},
             "roofline": {"bound": "valu", "kernel": kern, "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_TFLOPS,
-                         # the same algorithmic rate against the FMA-counted peak at the clock this box actually held
-                         "frac_at_measured_clock": achieved_tflops * 1e12 / (2.0 * peak_at_clock),
+                         "kernel_clock_ghz_profiled": prof_ghz,
+                         **({"frac_at_profiled_clock": achieved_tflops * 1e12 / (2.0 * cus * 4 * 32 * prof_ghz * 1e9)} if prof_ghz else {}),
                          # executed fp32 lane-flops (committed PMC instruction mix) over the live kernel time
                          "executed": (exec_flops / (kernel_ms * 1e-3) / 1e12) if exec_flops else None,
                          "executed_frac": (exec_flops / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS) if exec_flops else None,
@@ -415,10 +430,11 @@ def main():
                          "traffic_ratio": (traffic / alg_bytes) if traffic else None,
                          "kernel_ms": kernel_ms, "flops_per_unit": flops_per_unit,
                          "hbm": {"algorithmic_bytes": alg_bytes, "gbps": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak_gbps": 8000.0},
-                         "lane_ops": {"achieved": achieved_tflops * 1e12, "peak": PEAK_LANE_OPS,
-                                      "frac": achieved_tflops * 1e12 / PEAK_LANE_OPS,
-                                      "frac_at_measured_clock": achieved_tflops * 1e12 / peak_at_clock,
-                                      "note": note}},
+                         # the issue-slot view — one slot per flop — only where the kernel does not contract (strict path tracer,
+                         # Mandelbrot): for the fast path tracer the quotient of REFERENCE flops and unfused slots means nothing
+                         "lane_ops": ({"note": note} if contracted else
+                                      {"achieved": achieved_tflops * 1e12, "peak": PEAK_LANE_OPS,
+                                       "frac": achieved_tflops * 1e12 / PEAK_LANE_OPS, "note": note})},
         }
 
     # ---- secondary metric + strict-math leg: rank 0, N = 1, default headline only, outside the timed region ----------
@@ -508,6 +524,12 @@ def main():
         out["cpu_baseline"]["lavapipe_probe"] = lavapipe_probe()   # all four must exist for kind "reference"; they do not here
     if rank == 0:
         print(json.dumps(out), flush=True)
+    # A run that was meant to overlap its exchange (RCCL, not MC_BENCH_SYNC_EXCHANGE) but fell back to the synchronous path has
+    # measured something else: MC_BENCH_REQUIRE_ASYNC=1 (the multi-GPU self-test) turns that into a failure.
+    if n > 1 and backend == "nccl" and os.environ.get("MC_BENCH_REQUIRE_ASYNC") == "1" and ex.sync_mode:
+        ctx.close()
+        dist.destroy_process_group()
+        sys.exit("bench.py: the asynchronous exchange fell back to the synchronous path (MC_BENCH_REQUIRE_ASYNC=1)")
     ctx.close()
     if n > 1:
         dist.destroy_process_group()

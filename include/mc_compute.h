@@ -190,14 +190,15 @@ int mc_pathtrace_render_rgba8(mc_context* ctx, const mc_pathtrace_params* p, con
  * every other scene takes the generic kernel.  Bit 2 (MC_PT_SCENE_SPHERES_DISJOINT) — slab scenes: the three spheres are pairwise
  * disjoint with a margin; only then does MC_PT_MATH_FAST take the sample-pool kernel, which orders the spheres a shadow ray meets by
  * the projections of their centres (strict math does not depend on it).  Bit 3 (MC_PT_SCENE_LIGHT_ENCLOSED) — any scene: an
- * emissive sphere lies inside a non-emissive opaque sphere or pokes out of it by less than its own radius.  Such a light is seen only
- * through near-ties between the two surfaces (pathTracer.comp:325,333,420), which fast math decides differently from the reference
- * arithmetic far more often than its tolerance allows: an MC_PT_MATH_FAST request for such a scene is RENDERED WITH
- * THE STRICT KERNELS (bit-identical to the oracle), never silently outside the bound. */
+ * emissive sphere intersects a non-emissive diffuse sphere (or comes within 1.5 of its own radii of it), or is all but enclosed by a
+ * mirror sphere.  Next-event estimation at point-blank range through rays grazing the sphere they start on (pathTracer.comp:325-327,
+ * 420) makes such an image a collection of near-ties, which fast math decides differently from the reference arithmetic far more
+ * often than its tolerance allows: an MC_PT_MATH_FAST request for such a scene is RENDERED WITH THE STRICT KERNELS
+ * (bit-identical to the oracle), never silently outside the bound. */
 #define MC_PT_SCENE_SLAB 1u
 #define MC_PT_SCENE_LIGHTS_INSIDE 2u
 #define MC_PT_SCENE_SPHERES_DISJOINT 4u   /* slab scenes: the three spheres are pairwise disjoint (the fast sample-pool kernel's premise) */
-#define MC_PT_SCENE_LIGHT_ENCLOSED 8u     /* a light (all but) enclosed by an opaque sphere: fast math requests are rendered strict */
+#define MC_PT_SCENE_LIGHT_ENCLOSED 8u     /* a light intersecting a diffuse sphere / all but enclosed by a mirror: fast math requests are rendered strict */
 int mc_pathtrace_scene_class(const float* planes, uint32_t n_planes, const float* spheres, uint32_t n_spheres,
                              uint32_t* out_class);
 

@@ -223,7 +223,14 @@ def test_scene_classification_host_logic(B, O):
     assert B.pathtrace_scene_class(tilt, S) == 0
     nan = P.copy(); nan[1, 3] = np.nan
     assert B.pathtrace_scene_class(nan, S) == 0
-    assert B.pathtrace_scene_class(P[:5], S) == 0 and B.pathtrace_scene_class(P, S[:2]) == 0
+    assert B.pathtrace_scene_class(P[:5], S) == 0
+    # 1 .. 8 spheres take the slab kernels (round 4; the reference loops over spheres.length(), pathTracer.comp:127,403)
+    assert B.pathtrace_scene_class(P, S[:2]) == SLAB | DISJOINT                       # (no light: nothing to skip)
+    assert B.pathtrace_scene_class(P, S[1:]) == SLAB | INSIDE | DISJOINT
+    five = np.concatenate([S, S[:2] + np.float32([0, 0, 2.2] + [0] * 9)])             # two more spheres in front, clear of the others
+    assert B.pathtrace_scene_class(P, five) == SLAB | INSIDE | DISJOINT
+    nine = np.concatenate([S] * 3)
+    assert B.pathtrace_scene_class(P, nine) & SLAB == 0                               # beyond 8: the generic kernel
     assert B.pathtrace_scene_class(np.zeros((0, 12), np.float32), np.zeros((0, 12), np.float32)) == 0
     # argument validation
     out = C.c_uint32()
@@ -258,11 +265,14 @@ def test_fast_math_guard_classification_and_kernel_query(B, O):
         s[2, 11] = material
         if emissive_big:
             s[2, 4:7] = 1.0
+            s[0, 4:7] = 1.0     # (the third sphere too: the big light would sit within 1.5 of its radii of it)
         return B.pathtrace_scene_class(P, s) & ENC
-    assert with_gap(-0.3) and with_gap(0.0) and with_gap(0.5 * light[3]) and with_gap(0.99 * light[3])
-    assert not with_gap(1.05 * light[3]) and not with_gap(2 * light[3] + 0.5)
-    assert with_gap(0.01, material=2.0) and not with_gap(0.01, material=3.0)     # inside a mirror: yes; inside glass: well conditioned
-    assert not with_gap(0.01, emissive_big=True)                                  # two lights
+    # diffuse: intersecting (out < 2 r) or closer than 1.5 light radii (out < 3.5 r)
+    assert with_gap(-0.3) and with_gap(0.0) and with_gap(1.0 * light[3]) and with_gap(2.0 * light[3]) and with_gap(3.4 * light[3])
+    assert not with_gap(3.6 * light[3]) and not with_gap(2 * light[3] + 0.5)
+    # a mirror: only all but enclosed (out < 0.25 r); glass: never; two lights: never
+    assert with_gap(0.01, material=2.0) and with_gap(0.2 * light[3], material=2.0) and not with_gap(0.3 * light[3], material=2.0)
+    assert not with_gap(0.01, material=3.0) and not with_gap(0.01, emissive_big=True)
     # any scene, not only slab ones (the generic kernels have the same fast mode)
     assert B.pathtrace_scene_class(P[[2, 3, 0, 1, 4, 5]], S) == ENC
     # the reference scene: pool kernel in both modes, the round-synchronous kernels for what the pool kernel does not take

@@ -75,9 +75,9 @@ def test_clock_probe_reports_a_plausible_shader_clock(ctx):
 
 
 def test_reserved_flag_bits_are_refused(ctx, B):
-    """Stray flag bits never select a kernel silently (bit 1 was the removed lane-regrouping experiment; bits 6-7 and 20+ are
+    """Stray flag bits never select a kernel silently (bit 1 was the removed lane-regrouping experiment; bit 7 and bits 20+ are
     unassigned): MC_ERR_INVALID_ARGUMENT whatever the scene size."""
-    for flags in (2, 1 << 6, 1 << 20, 1 << 23, 1 << 31):
+    for flags in (2, 1 << 7, 1 << 20, 1 << 23, 1 << 31):
         with pytest.raises(B.McError) as e:
             ctx.pathtrace(B.pathtrace_params(8, 8, 4, flags=flags))
         assert e.value.status == 1    # MC_ERR_INVALID_ARGUMENT

@@ -118,8 +118,75 @@ def test_multi_two_devices_equal_single(ctx, B):
 def test_bench_two_gpus_rccl_verify(extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--verify"] + extra
-    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=dict(os.environ, MC_BENCH_REQUIRE_ASYNC="1"))
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["config"]["backend"] == "nccl" and d["config"]["verified_equal_to_single_gpu"] is True
     assert d["config"]["gather_bytes_per_rank"] > 0
+    assert d["config"]["exchange_async"] is True      # the overlapped exchange ran — not its synchronous fallback
+
+
+def test_asynchronous_exchange_ordering_with_a_stub_collective(ctx, B, monkeypatch):
+    """the asynchronous RCCL branch of sharding.Exchange — dist.gather(async_op=True), Work.wait() under the side
+    stream, re-assembly on the side stream, two buffer sets reused through events — has never run on hardware with N > 1 (RCCL refuses
+    two ranks on one GPU, and the gloo rehearsals take the synchronous branch).  Here it runs on ONE GPU against a stub collective with
+    the semantics torch documents for the NCCL backend: the copy is ordered after the work queued on the caller's current stream,
+    executes on a THIRD stream (made slow, so that an ordering mistake shows), and Work.wait() makes the current stream wait for it.
+    Six steps with a different image each; every step's re-assembled image must be that step's, bit for bit: the render stream may not
+    overwrite a tile the collective still reads, nor rank 0's re-assembly read a receive buffer the next collective already writes."""
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    S = entry.load_package().sharding
+    n, W, H = 2, 64, 48
+    blk = S.ROW_BLOCK
+    pad = S.padded_tile_rows(H, n)
+    coll = torch.cuda.Stream()
+    remote_tiles = {}           # what "rank 1" sends in each step
+    calls = []
+
+    class StubWork:
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+            return True
+
+    def stub_gather(tensor, gather_list=None, dst=0, async_op=False, group=None):
+        assert async_op, "the asynchronous branch must be the one that runs"
+        issued = torch.cuda.Event()
+        issued.record()                                  # after everything queued on the caller's (render) stream
+        done = torch.cuda.Event()
+        with torch.cuda.stream(coll):
+            coll.wait_event(issued)
+            torch.cuda._sleep(20_000_000)                # ~10 ms: the collective is slow, the render of the next steps is not
+            gather_list[0].copy_(tensor)
+            gather_list[1].copy_(remote_tiles[len(calls)])
+            done.record()
+        calls.append(len(calls))
+        return StubWork(done)
+
+    monkeypatch.setattr(dist, "get_backend", lambda *a, **k: "nccl")
+    monkeypatch.setattr(dist, "gather", stub_gather)
+    monkeypatch.delenv("MC_BENCH_SYNC_EXCHANGE", raising=False)
+    ex = S.Exchange(0, n, (pad, W, 4), torch.float32, "cuda")
+    assert not ex.sync_mode and not ex.gloo
+    steps = 6
+    outs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(steps)]
+    rows = [S.rank_rows(H, r, n) for r in range(n)]
+    full = [torch.arange(H * W * 4, dtype=torch.float32, device="cuda").reshape(H, W, 4) * (i + 1) + i for i in range(steps)]
+    for i in range(steps):
+        remote = torch.zeros((pad, W, 4), dtype=torch.float32, device="cuda")
+        remote[:len(rows[1])] = full[i][rows[1]]
+        remote_tiles[i] = remote
+    for i in range(steps):
+        t = ex.tile(i)                                   # (waits, on the device, for the exchange that last used this buffer set)
+        t.zero_()
+        t[:len(rows[0])] = full[i][rows[0]]              # "render" step i into the tile on the current stream
+        ex.submit(i, lambda recv, stream, i=i: S.assemble_device(ctx, recv, W, H, n, outs[i], stream))
+    ex.finish()
+    torch.cuda.synchronize()
+    assert calls == list(range(steps)) and not ex.sync_mode, "the exchange fell back to the synchronous path"
+    for i in range(steps):
+        assert torch.equal(outs[i], full[i]), f"step {i}: the re-assembled image is not that step's"

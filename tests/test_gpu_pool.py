@@ -56,16 +56,45 @@ def test_outside_its_domain_the_round_synchronous_kernels_run(ctx, B):
     """Partial sample ranges (the accumulator continues in the buffer), forced widths, tiles that cut a wave tile, scenes that are
     not a closed box: the default flags and MC_PT_NO_POOL_KERNEL must give the same bits, i.e. the same kernel ran."""
     W, H, spp = 40, 24, 19
-    cases = [dict(sample_begin=0, sample_end=7), dict(row_begin=5, row_end=17), dict(row_begin=0, row_end=23)]
+    cases = [dict(row_begin=5, row_end=17), dict(row_begin=0, row_end=23)]
     for kw in cases:
         assert np.array_equal(bits(fast(ctx, B, W, H, spp, **kw)), bits(fast(ctx, B, W, H, spp, flags=B.PT_NO_POOL_KERNEL, **kw))), kw
     for s in (1, 4, 16):
         a = fast(ctx, B, W, H, spp, flags=B.pt_force_s(s))
         assert np.array_equal(bits(a), bits(fast(ctx, B, W, H, spp, flags=B.pt_force_s(s) | B.PT_NO_POOL_KERNEL))), s
-    # progressive ranges still compose bit-exactly in fast math (round-synchronous kernels on both sides)
-    part = fast(ctx, B, W, H, spp, sample_begin=0, sample_end=7)
-    part = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, sample_begin=7, sample_end=spp), acc=part)
-    assert np.array_equal(bits(part), bits(fast(ctx, B, W, H, spp, flags=B.PT_NO_POOL_KERNEL)))
+    # progressive ranges of the round-synchronous kernels still compose bit-exactly in fast math
+    F = B.PT_NO_POOL_KERNEL
+    part = fast(ctx, B, W, H, spp, flags=F, sample_begin=0, sample_end=7)
+    part = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, flags=F, sample_begin=7, sample_end=spp), acc=part)
+    assert np.array_equal(bits(part), bits(fast(ctx, B, W, H, spp, flags=F)))
+
+
+def test_fast_progressive_ranges_run_the_pool_kernel(ctx, B, O):
+    """SURVEY §8(f)3 in fast math (round 4): a sample range is rendered by the pool kernel and its share added to the stored
+    accumulator.  The split render agrees with the one-launch render to fp32 reassociation (same samples, same arithmetic per sample:
+    no forked paths), is deterministic, composes identically on every tiling, and the one-launch image is what it was."""
+    W, H, spp = 64, 40, 100
+    assert B.pathtrace_select_kernel(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, sample_begin=20, sample_end=60)).kernel == B.PT_KERNEL_POOL
+    whole = fast(ctx, B, W, H, spp)
+
+    def split(cuts, **kw):
+        acc = None
+        for s0, s1 in zip(cuts[:-1], cuts[1:]):
+            acc = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, sample_begin=s0, sample_end=s1, **kw), acc=acc)
+        return acc
+    for cuts in ([0, 20, 40, 60, 80, 100], [0, 7, 100], [0, 99, 100]):
+        parts = split(cuts)
+        assert np.array_equal(bits(parts), bits(split(cuts))), cuts                        # deterministic
+        d = np.abs(parts[..., :3].astype(np.float64) - whole[..., :3].astype(np.float64))
+        assert d.max() <= 2e-3, (cuts, d.max())                                            # 8-bit units: reassociation only
+    # the same split on two row tiles = the same split on the whole image, bit for bit
+    cuts = [0, 33, 100]
+    top, bottom = split(cuts, row_begin=0, row_end=16), split(cuts, row_begin=16, row_end=H)
+    assert np.array_equal(bits(np.concatenate([top, bottom])), bits(split(cuts)))
+    # an unfinished range leaves the raw accumulator (no tonemap yet): the oracle's partial sum within the fast tolerance
+    half = fast(ctx, B, W, H, spp, sample_begin=0, sample_end=50)[..., :3].astype(np.float64)
+    ref = O.pathtrace(W, H, spp, math_mode=O.MATH_LIBM, sample_begin=0, sample_end=50)[..., :3].astype(np.float64)
+    assert np.abs(half - ref).mean() < 2e-3 * max(1.0, ref.mean())
 
 
 def test_pool_kernel_within_the_fast_tolerance_of_the_oracle(ctx, B, O):

@@ -212,3 +212,59 @@ def test_scene_beyond_the_lds_store_renders_from_memory(ctx, B, O):
     for flags in (B.PT_SCENE_IN_LDS, B.pt_precision(B.PT_PREC_DS)):
         with pytest.raises(B.McError):
             ctx.pathtrace(B.pathtrace_params(W, H, spp, flags=flags), planes=planes, spheres=spheres)
+
+
+def box_scene(O, n_spheres, rng, lights=1):
+    """The reference room with `n_spheres` pairwise disjoint spheres placed on a jittered grid inside it (diffuse, mirror, glass),
+    `lights` of them small emitters under the ceiling — what the specialised slab / closed-box / sample-pool kernels take for
+    1 .. 8 spheres (round 4; pathTracer.comp:127,403 loop over spheres.length())."""
+    planes = O.DEFAULT_PLANES.copy().reshape(6, 12)
+    cells = [(x, y, z) for y in (-1.1, 0.4) for z in (-1.6, 0.6) for x in (-1.4, 1.4)]
+    order = rng.permutation(len(cells))[:n_spheres]
+    spheres = np.zeros((n_spheres, 12), np.float32)
+    for k, c in enumerate(order):
+        spheres[k, 0:3] = np.float32(cells[c]) + rng.uniform(-0.15, 0.15, 3).astype(np.float32)
+        spheres[k, 3] = np.float32(rng.uniform(0.25, 0.6))
+        spheres[k, 8:11] = rng.uniform(0.3, 0.999, 3).astype(np.float32)
+        spheres[k, 11] = float(rng.choice([1, 2, 3]))
+    for k in range(lights):
+        spheres[k, 0:3] = np.float32([-1.2 + 2.4 * k / max(1, lights - 1) if lights > 1 else 0.0, 1.55, -0.3])
+        spheres[k, 3] = np.float32(0.2)
+        spheres[k, 4:7] = rng.uniform(40, 110, 3).astype(np.float32)
+        spheres[k, 8:11] = 0
+        spheres[k, 11] = 1.0
+    return planes, rng.permutation(spheres)      # (the light at any index)
+
+
+@pytest.mark.parametrize("n_spheres,lights", [(1, 1), (2, 1), (4, 1), (5, 2), (8, 1), (8, 3)])
+def test_box_with_one_to_eight_spheres_runs_the_specialised_kernels(ctx, B, O, n_spheres, lights):
+    """SURVEY §8(f)4 for the fast path: the axis-aligned box with 1 .. 8 spheres takes the slab / closed-box /
+    sample-pool kernels (instantiated per sphere count) instead of the generic one.  Strict: the pool kernel, the round-synchronous
+    slab kernel at every width and the generic kernel all equal the oracle bit for bit.  Fast: inside the 0.5 / 4 bound."""
+    rng = np.random.default_rng(40 + 10 * n_spheres + lights)
+    planes, spheres = box_scene(O, n_spheres, rng, lights)
+    cls = B.pathtrace_scene_class(planes, spheres)
+    assert cls == B.PT_SCENE_SLAB | B.PT_SCENE_LIGHTS_INSIDE | B.PT_SCENE_SPHERES_DISJOINT, cls
+    W, H, spp = 40, 24, 37
+    ref = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC)
+    p = B.pathtrace_params(W, H, spp)
+    assert B.pathtrace_select_kernel(p, planes, spheres).kernel == B.PT_KERNEL_POOL
+    assert np.array_equal(bits(ctx.pathtrace(p, planes=planes, spheres=spheres)), bits(ref))
+    for flags in (B.PT_NO_POOL_KERNEL, B.pt_force_s(1), B.pt_force_s(4), B.pt_force_s(16), B.PT_GENERIC_KERNEL):
+        out = ctx.pathtrace(B.pathtrace_params(W, H, spp, flags=flags), planes=planes, spheres=spheres)
+        assert np.array_equal(bits(out), bits(ref)), flags
+    # progressive ranges and an interleaved row tile through the strict pool kernel
+    part = ctx.pathtrace(B.pathtrace_params(W, H, spp, sample_begin=0, sample_end=20), planes=planes, spheres=spheres)
+    part = ctx.pathtrace(B.pathtrace_params(W, H, spp, sample_begin=20, sample_end=spp), planes=planes, spheres=spheres, acc=part)
+    assert np.array_equal(bits(part), bits(ref))
+    # fast math: the pool kernel and the round-synchronous closed-box kernel against the oracle with libm, at the sample count the
+    # bound is stated for (K2's 500 spp: a forked sample's weight is part of the bound)
+    W, H, spp = 300, 200, 500
+    libm = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_LIBM)[..., :3].astype(np.float64)
+    for flags in (0, B.PT_NO_POOL_KERNEL):
+        q = B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, flags=flags)
+        assert B.pathtrace_select_kernel(q, planes, spheres).kernel == (B.PT_KERNEL_BOX if flags else B.PT_KERNEL_POOL)
+        d = ctx.pathtrace(q, planes=planes, spheres=spheres)[..., :3].astype(np.float64) - libm
+        rmse, p999 = float(np.sqrt((d ** 2).mean())), float(np.percentile(np.sqrt((d ** 2).sum(-1)), 99.9))
+        print(f"{n_spheres} spheres / {lights} lights, flags {flags}: fast vs oracle(libm) rmse {rmse:.4f}  p99.9 L2 {p999:.3f}  mean {d.mean():+.5f}")
+        assert np.isfinite(d).all() and rmse <= 0.5 and p999 <= 4.0 and abs(d.mean()) < 0.03, (flags, rmse, p999)

@@ -10,7 +10,7 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(pathtrace_kernel<[^>]*>|pathtrace_pool_kernel<[^>]*>|pathtrace_regroup_kernel<[^>]*>|mandelbrot_kernel<.*?, \d+>|convert_rgba8_kernel|deinterleave_rows_kernel)", name)
+    m = re.search(r"(pathtrace_kernel<[^>]*>|pathtrace_pool_kernel<[^>]*>|mandelbrot_kernel<.*?, \d+>|convert_rgba8_kernel|deinterleave_rows_kernel)", name)
     return m.group(1) if m else None
 
 
@@ -36,6 +36,8 @@ def main():
             if not k:
                 continue
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("End_Timestamp"):   # the launch's duration in the SAME pass: its clock
+                agg[k]["_duration_ns_with_GRBM"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
             meta[k] = {"grid": r["Grid_Size"], "workgroup": r["Workgroup_Size"], "lds_bytes": r["LDS_Block_Size"],
                        "arch_vgpr": r["VGPR_Count"], "sgpr": r["SGPR_Count"]}
         for k, v in agg.items():
@@ -51,6 +53,10 @@ def main():
             d["active_lanes_per_valu_inst"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]
         if "GRBM_GUI_ACTIVE" in c:
             d["gpu_cycles_per_xcd"] = c["GRBM_GUI_ACTIVE"] / 8.0
+            if c.get("_duration_ns_with_GRBM"):
+                # the shader clock the kernel ITSELF held (cycles per XCD / duration of the same launches) — not the clock a probe
+                # kernel reads under its own load afterwards (profiles/r04_k3_clock.txt)
+                d["kernel_clock_ghz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / c["_duration_ns_with_GRBM"]
         if "WRITE_SIZE" in c:
             d["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024.0    # WRITE_SIZE is in KB; exact for 16-B stores (MI355X_MICROARCH.md §HBM)
         if "SQ_INSTS_VALU_ADD_F32" in c:

@@ -22,14 +22,15 @@ inline v3 h_cross(v3 a, v3 b) { return v3{a.y * b.z - b.y * a.z, a.z * b.x - b.z
 inline v3 h_normalize(v3 a) { return h_muls(a, 1.0f / sqrtf(h_dot(a, a))); }
 
 // Slab specialisation is exact only when (see pathtrace_kernel.h, intersect()):
-//   * there are exactly 6 planes and 3 spheres (the shape the specialised kernels are unrolled for),
+//   * there are exactly 6 planes and 1 .. 8 spheres (the shapes the specialised kernels are instantiated for: the reference scene
+//     has 3, pathtracerApp.h:36-38; pathTracer.comp:127,403 loop over spheres.length()),
 //   * every plane normal is +-1 along one axis and +-0 along the others, with a non-zero offset w,
 //   * no two planes share (axis, sign), and
 //   * plane indices are grouped by axis in x, y, z order, so visiting the axes in that order compares
 //     candidates in the reference's plane-index order (ties on `d < t` keep the earlier plane).
 bool analyse_slabs(const float* planes, uint32_t n_planes, uint32_t n_spheres, pt::SceneArgs& sc) {
     for (int a = 0; a < 3; a++) { sc.slab_id_pos[a] = sc.slab_id_neg[a] = -1; sc.slab_w_pos[a] = sc.slab_w_neg[a] = 0.0f; }
-    if (n_planes != 6 || n_spheres != 3) return false;
+    if (n_planes != 6 || n_spheres < 1 || n_spheres > (uint32_t)pt::kMaxSlabSpheres) return false;
     int axis_of[6];
     for (uint32_t i = 0; i < n_planes; i++) {
         const float* pl = planes + 12 * i;
@@ -103,11 +104,11 @@ int choose_S(uint64_t pixels, uint32_t samples) {
 
 }  // namespace
 
-// The three spheres of a slab scene pairwise disjoint, with a margin far above fp32 rounding of the kernel's squared distances
+// The spheres of a slab scene pairwise disjoint, with a margin far above fp32 rounding of the kernel's squared distances
 // (the fast sample-pool kernel orders the spheres a shadow ray meets by their centres' projections, shadow_visible_disjoint).
-static bool spheres_disjoint(const float* spheres) {
-    for (uint32_t i = 0; i < 3; i++)
-        for (uint32_t j = i + 1; j < 3; j++) {
+static bool spheres_disjoint(const float* spheres, uint32_t n_spheres) {
+    for (uint32_t i = 0; i < n_spheres; i++)
+        for (uint32_t j = i + 1; j < n_spheres; j++) {
             const float* si = spheres + 12 * i;
             const float* sj = spheres + 12 * j;
             const double dx = (double)si[0] - sj[0], dy = (double)si[1] - sj[1], dz = (double)si[2] - sj[2];
@@ -117,16 +118,22 @@ static bool spheres_disjoint(const float* spheres) {
     return true;
 }
 
-// A light (all but) ENCLOSED by an opaque sphere — found by tools/fuzz_fast.py: 0.01 of a light poking out of a diffuse sphere — is seen
-// only through grazing decisions between the two surfaces, each worth a firefly of the light's full emission: which of the two roots
-// is nearer decides the sample, and the fast kernels' contracted arithmetic decides 2-4 % of the pixels the other way (RMSE 3.6 / p99.9 77
-// against the 0.5 / 4 bound at 300x200x256) while the oracle's own two evaluations stay inside it (0.17 / 0.48).  Fast math cannot hold
+// A light that INTERSECTS a diffuse sphere, or is (all but) enclosed by an opaque one — found by tools/fuzz_fast.py: 0.01 of a light poking
+// out of a diffuse sphere.  Next-event estimation from the sphere's surface next to the intersection circle samples the light at point-blank
+// range through rays that graze the sphere they start on: whether :325-:327 keep such a ray's far root decides samples worth a firefly of
+// the light's full emission, and the fast kernels' contracted discriminants decide differently from the reference arithmetic far more
+// often than the tolerance allows — RMSE 3.6 / p99.9 77 against the 0.5 / 4 bound at 300 x 200 x 256 in the case found, still 0.7 / 14
+// with the light three quarters outside — while the oracle's own two evaluations stay inside it (0.17 / 0.48).  Fast math cannot hold
 // its tolerance there, so it does not run there: the host classifies the scene (mc_pathtrace_scene_class bit 3) and renders an
-// MC_PT_MATH_FAST request with the strict kernels.  Criterion: an emissive sphere i whose outermost point lies less than
-// kEnclosedMargin * r_i outside a non-emissive opaque (material 1 / 2) sphere j, or inside it: |c_i - c_j| + r_i - r_j < margin * r_i.
-// (A light inside a GLASS sphere is well conditioned — next-event estimation never passes the glass, :420 — and two lights inside each
-// other both emit.)  Calibration of the margin: tools/enclosed_light_sweep.py, profiles/r04_enclosed_light_sweep.txt.
-constexpr double kEnclosedMargin = 1.0;
+// MC_PT_MATH_FAST request with the strict kernels.  Criterion, calibrated by tools/enclosed_light_sweep.py
+// (profiles/r04_enclosed_light_sweep.txt: the fast kernels against the oracle with the light moved from deep inside the sphere to well
+// clear of it), with out = |c_i - c_j| + r_i - r_j = how far emissive sphere i pokes out of the non-emissive sphere j (2 r_i: they touch):
+//   * j diffuse (material 1):  out < (2 + kLightGapMargin) r_i — the spheres intersect or are closer than kLightGapMargin light radii
+//     (measured: inside the bound again from the touching point on, with the margin on top);
+//   * j a mirror (material 2): out < kMirrorMargin r_i — all but enclosed (a mirror takes no next-event estimation, :432: measured inside
+//     the bound for every position but the light's last sliver);
+//   * j of glass: never (next-event estimation does not pass glass, :420; the light is seen through refraction only), two lights: never.
+constexpr double kLightGapMargin = 1.5, kMirrorMargin = 0.25;
 bool light_nearly_enclosed(const float* spheres, uint32_t n_spheres) {
     for (uint32_t i = 0; i < n_spheres; i++) {
         const float* si = spheres + 12 * i;
@@ -134,11 +141,13 @@ bool light_nearly_enclosed(const float* spheres, uint32_t n_spheres) {
         for (uint32_t j = 0; j < n_spheres; j++) {
             const float* sj = spheres + 12 * j;
             if (j == i || h_dot(v3{sj[4], sj[5], sj[6]}, v3{sj[4], sj[5], sj[6]}) > 0.0f) continue;
-            if (floorf(sj[11] + 0.5f) == 3.0f) continue;                                    // glass
+            const float mat = floorf(sj[11] + 0.5f);
+            if (mat != 1.0f && mat != 2.0f) continue;                                       // glass; unknown codes keep their ray (no surface)
             const double dx = (double)si[0] - sj[0], dy = (double)si[1] - sj[1], dz = (double)si[2] - sj[2];
             const double ri = std::fabs((double)si[3]), rj = std::fabs((double)sj[3]);
             const double out = std::sqrt(dx * dx + dy * dy + dz * dz) + ri - rj;           // how far the light pokes out of sphere j
-            if (!(out >= kEnclosedMargin * ri)) return true;                                // (also NaN)
+            const double limit = mat == 1.0f ? (2.0 + kLightGapMargin) * ri : kMirrorMargin * ri;
+            if (!(out >= limit)) return true;                                               // (also NaN)
         }
     }
     return false;
@@ -153,7 +162,7 @@ uint32_t pathtrace_scene_class(const float* planes, uint32_t n_planes, const flo
     set_camera(a);
     const uint32_t ill = light_nearly_enclosed(spheres, n_spheres) ? MC_PT_SCENE_LIGHT_ENCLOSED : 0u;
     if (!analyse_slabs(planes, n_planes, n_spheres, a.scene)) return ill;
-    return 1u | (lights_inside_box(a.scene, spheres, n_spheres, a.cam_o, a.lc) ? 2u : 0u) | (spheres_disjoint(spheres) ? 4u : 0u) | ill;
+    return 1u | (lights_inside_box(a.scene, spheres, n_spheres, a.cam_o, a.lc) ? 2u : 0u) | (spheres_disjoint(spheres, n_spheres) ? 4u : 0u) | ill;
 }
 
 namespace {
@@ -216,7 +225,7 @@ int pathtrace_plan(const mc_pathtrace_params* p, const float* planes, uint32_t n
     a.scene.n_planes = n_planes; a.scene.n_spheres = n_spheres;
     const bool slab = prec == 0 && analyse_slabs(planes, n_planes, n_spheres, a.scene) && !(p->flags & MC_PT_GENERIC_KERNEL);
     plan.slab = slab;
-    if (slab) {   // 6 planes + 3 spheres: the records travel in the kernel-argument segment, planes in canonical
+    if (slab) {   // 6 planes + 1 .. 8 spheres: the records travel in the kernel-argument segment, planes in canonical
                   // slab order (x-,x+,y-,y+,z-,z+) so that the kernel's plane id is 2*axis + (d[axis] > 0)
         for (int ax = 0; ax < 3; ax++) {
             std::memcpy(a.scene.obj + 12 * (2 * ax), planes + 12 * a.scene.slab_id_neg[ax], sizeof(float) * 12);
@@ -230,7 +239,7 @@ int pathtrace_plan(const mc_pathtrace_params* p, const float* planes, uint32_t n
             if (h_dot(e, e) > 0.0f) a.scene.emissive_mask |= 1u << i;
         }
         a.scene.nee_skip_planes = lights_inside_box(a.scene, spheres, n_spheres, a.cam_o, a.lc) ? 1u : 0u;
-        for (uint32_t i = 0; i < 3; i++) {   // c_i - lc and its squared length, as dot() associates: (x*x + y*y) + z*z
+        for (uint32_t i = 0; i < n_spheres; i++) {   // c_i - lc and its squared length, as dot() associates: (x*x + y*y) + z*z
             const float* sp = spheres + 12 * i;
             const float ox = sp[0] - a.lc.x, oy = sp[1] - a.lc.y, oz = sp[2] - a.lc.z;
             a.cam_oc[i][0] = ox; a.cam_oc[i][1] = oy; a.cam_oc[i][2] = oz;
@@ -252,7 +261,7 @@ int pathtrace_plan(const mc_pathtrace_params* p, const float* planes, uint32_t n
                 const float c = a.scene.obj[12 * i + k];
                 if (!(c >= 0.0f && c <= 1.0f)) a.scene.emit_skip_ok = 0u;     // also rejects NaN
             }
-        a.scene.spheres_disjoint = spheres_disjoint(spheres) ? 1u : 0u;
+        a.scene.spheres_disjoint = spheres_disjoint(spheres, n_spheres) ? 1u : 0u;
         // closed-box fast kernel: no ray may ever leave the box (pathtrace_kernel.h, intersect_box)
         a.scene.box_ok = (a.scene.nee_skip_planes && a.scene.materials_known && !glass_wall && a.scene.emit_skip_ok) ? 1u : 0u;
     } else {
@@ -279,20 +288,18 @@ int pathtrace_plan(const mc_pathtrace_params* p, const float* planes, uint32_t n
     }
     if (slab && a.scene.box_ok && !(p->flags & MC_PT_NO_BOX_KERNEL)) {
         if (fast) variant = 3;   // the closed-box round-synchronous kernels (scene facts at compile time)
-        // The sample-pool kernels (pathtrace_pool.h): fast math whole sample ranges only (the pixel sums are formed inside the launch), the
-        // automatic width; 16 lanes per pixel and batch (2 x 2 pixels per wave) for every image size — never a function of the tile.
+        // The sample-pool kernels (pathtrace_pool.h): the automatic width; 16 lanes per pixel and batch (2 x 2 pixels per wave) for every image size — never a function of the tile.
         // Fast math adds a pixel's radiance in an order that depends on the wave's schedule, so it is selected only for tiles whose
         // wave tiles are those of the whole image — a wave's pixels, hence its schedule, are then the same for every tiling:
         // N-GPU output == 1-GPU output, bit for bit.  The strict variant adds in sample order whatever the tile.
         const uint32_t th = 2u;   // WaveTile<16>::h
-        // (strict: any sample range — the ordered sum continues from the stored accumulator exactly as the round-synchronous kernels'
-        // does; fast: whole ranges only, its per-lane partial sums would make a progressive render differ from a one-launch one)
-        const bool whole_range = !fast || (p->sample_begin == 0u && p->sample_end == p->spp);
+        // (any sample range: strict continues the ordered sum from the stored accumulator exactly as the round-synchronous kernels do;
+        // fast adds the range's share to it — since round 4; before, fast ranges fell back to the round-synchronous kernel)
         const bool aligned = p->row_begin % th == 0u && (a.row_block == 0u || (a.row_block % th == 0u && a.row_stride % th == 0u)) &&
                              (p->row_end % th == 0u || p->row_end == p->height);
         const bool fits = p->max_depth >= 1u && (uint64_t)p->spp * p->max_depth < (1ull << 32) && p->width < (1u << 24);
         // (the fast pool kernel orders a shadow ray's spheres by their centres' projections: disjoint spheres only)
-        if (auto_width && !(p->flags & MC_PT_NO_POOL_KERNEL) && whole_range && (aligned || !fast) && fits &&
+        if (auto_width && !(p->flags & MC_PT_NO_POOL_KERNEL) && (aligned || !fast) && fits &&
             (!fast || a.scene.spheres_disjoint))
             variant = 4;
     }

@@ -41,6 +41,7 @@ namespace pt {
 
 constexpr int kMaxPlanes = 16;
 constexpr int kMaxSpheres = 16;
+constexpr int kMaxSlabSpheres = 8;   // the slab / closed-box / sample-pool kernels are instantiated for 1 .. 8 spheres
 
 struct v3 {
     float x, y, z;
@@ -80,7 +81,7 @@ struct SceneArgs {
     const float* d_obj_derived;
     const uint32_t* d_emissive;
     uint32_t n_emissive;
-    // Fast math, slab scenes: non-zero when the three spheres are pairwise disjoint with a margin (pathtrace.hip): the order of
+    // Fast math, slab scenes: non-zero when the spheres are pairwise disjoint with a margin (pathtrace.hip): the order of
     // two spheres along any ray is then the order of their centres' projections (shadow_visible_disjoint)
     uint32_t spheres_disjoint;
     uint32_t pad3, pad4;
@@ -92,7 +93,7 @@ struct PTArgs {
     v3 cam_o, cam_d, cx, cy, lc;
     // slab kernels: sphere centre - lc and its squared length for the camera ray's intersect (:317-:318 with o = lc), the same
     // IEEE operations evaluated once on the host — wave-uniform values that would otherwise sit in (spilled) vector registers
-    float cam_oc[3][3], cam_occ[3];
+    float cam_oc[kMaxSlabSpheres][3], cam_occ[kMaxSlabSpheres];
     // fast mode: 1/W, 1/H, 1/spp (host: 1.0f / x) for the sensor position (:358-:359) and accrad / samps.y (:452) — uniform
     // reciprocals the kernel would otherwise form with v_rcp_f32 and carry in vector registers through every round
     float inv_W, inv_H, inv_spp;
@@ -357,9 +358,10 @@ __device__ __forceinline__ float to_vgpr(float uniform) {
     asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform));
     return v;
 }
-struct HotSlab {
+template <int NS> struct HotSlabN {
+    static constexpr int ns = NS;   // spheres of the scene (the six planes are the slab form)
     float W_pos[3], W_negm[3];   // w of the +e_a plane; MINUS w of the -e_a plane (see intersect_slab)
-    float c[3][3], r2[3];        // sphere centres, radius^2 (the fp32 product of pathTracer.comp:318)
+    float c[NS][3], r2[NS];      // sphere centres, radius^2 (the fp32 product of pathTracer.comp:318)
     float eps, tri_eps, inf;     // kEps, kTriEps, kInf
     // InVgpr = false leaves the values to the compiler (SGPR operands): for kernels without the register headroom.
     // WPosInVgpr: only W_pos in vector registers — the select `d_a > 0 ? W_pos : W_negm` then is ONE v_cndmask (SGPR, VGPR, vcc)
@@ -369,7 +371,7 @@ struct HotSlab {
 #pragma unroll
         for (int a = 0; a < 3; a++) { W_pos[a] = (InVgpr || WPosInVgpr) ? to_vgpr(sc.slab_w_pos[a]) : sc.slab_w_pos[a]; W_negm[a] = put(-sc.slab_w_neg[a]); }
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
+        for (int i = 0; i < NS; i++) {
 #pragma unroll
             for (int k = 0; k < 3; k++) c[i][k] = put(sc.obj[12 * (6 + i) + k]);
             r2[i] = put(sc.r2[i]);
@@ -386,8 +388,8 @@ struct HotSlab {
 // Closed (fast math, SceneArgs::box_ok, origin inside the box): the nearest facing plane IS a hit — the |d_a| > 1e-7 / t < 1e20
 // tests of :119 / :336 can only fail for a ray that runs along a wall it starts on to within 1e-7, or a NaN ray (which then
 // gathers nothing: every later comparison with its NaN t is false) — so they and the final "anything hit?" select are dropped.
-template <bool Fast, bool Closed = false, bool OccR2 = false, int StatsBase = -1>   // OccR2: occ[i] holds |c_i - o|^2 - r_i^2 (fast math)
-__device__ __forceinline__ int intersect_slab(const HotSlab& h, v3 o, v3 d, float& t_out, bool shadow_skip_planes,
+template <bool Fast, bool Closed = false, bool OccR2 = false, int StatsBase = -1, int NS = 3>   // OccR2: occ[i] holds |c_i - o|^2 - r_i^2 (fast math)
+__device__ __forceinline__ int intersect_slab(const HotSlabN<NS>& h, v3 o, v3 d, float& t_out, bool shadow_skip_planes,
                                               const float* occ = nullptr,     // occ[i] = dot(c_i - o, c_i - o) and
                                               const v3* oc_at_o = nullptr) {  // oc_at_o[i] = c_i - o if the caller has them
     MC_PT_DECISION_FP
@@ -436,7 +438,7 @@ __device__ __forceinline__ int intersect_slab(const HotSlab& h, v3 o, v3 d, floa
     // each serve a handful of lanes.  Bit-identical, 10 instructions fewer on paper, and slower: 14.96 against 14.69 ms.  The
     // per-sphere blocks are skipped for the whole wave more often than the merged one, and the selects are paid by every lane.)
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < NS; i++) {
         v3 oc = oc_at_o ? oc_at_o[i] : v3{h.c[i][0], h.c[i][1], h.c[i][2]} - o;   // :317
         float b = dot(oc, d);                                                // :318
         float det = OccR2 ? b * b - occ[i] : (b * b - (occ ? occ[i] : dot(oc, oc))) + h.r2[i];
@@ -461,12 +463,12 @@ __device__ __forceinline__ int intersect_slab(const HotSlab& h, v3 o, v3 d, floa
 // The reference keeps a later candidate only if it is STRICTLY nearer, so sphere li wins iff its root dd_li is finite,
 // strictly below every root of the spheres before it and not above any root of the spheres after it.  dd_k is the value the
 // loop assigns for sphere k (:319-327), 1e20 when there is none.  Same comparisons on the same values: exact.
-template <bool Fast>
-__device__ __forceinline__ bool shadow_reaches_sphere(const HotSlab& h, v3 o, v3 d, int li, v3 oc_li, const float* occ) {
+template <bool Fast, int NS>
+__device__ __forceinline__ bool shadow_reaches_sphere(const HotSlabN<NS>& h, v3 o, v3 d, int li, v3 oc_li, const float* occ) {
     MC_PT_DECISION_FP
-    float dd[3];
+    float dd[NS];
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < NS; i++) {
         // centre - o of the light (:408) and all three squared lengths were formed by the caller: the same operations
         const v3 oc = i == li ? oc_li : v3{h.c[i][0], h.c[i][1], h.c[i][2]} - o;   // :317
         float b = dot(oc, d);                                                // :318
@@ -482,12 +484,17 @@ __device__ __forceinline__ bool shadow_reaches_sphere(const HotSlab& h, v3 o, v3
         }
         dd[i] = r;
     }
-    // li is a constant of the caller's unrolled light loop
-    if (Fast && li == 2) return dd[2] < dd[0] && dd[2] < dd[1];   // (dd[k] <= 1e20: the third test is implied; two compares,
-                                                                    // not fminf's two canonicalising v_max + v_min + compare)
-    if (li == 2) return dd[2] < dd[0] && dd[2] < dd[1] && dd[2] < h.inf;
-    if (li == 1) return dd[1] < dd[0] && !(dd[2] < dd[1]) && dd[1] < h.inf;
-    return !(dd[1] < dd[0]) && !(dd[2] < dd[0]) && dd[0] < h.inf;
+    // li is a constant of the caller's unrolled light loop.  Strictly below every EARLIER sphere's root, not above any LATER one's
+    // (:333 keeps a later candidate only if it is strictly nearer), and finite.  (Fast, the last sphere: dd[k] <= 1e20 makes the
+    // finiteness test implied when there is an earlier sphere to beat.)
+    bool nearest = true;
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+        if (k < li) nearest = nearest && dd[li] < dd[k];
+        else if (k > li) nearest = nearest && !(dd[k] < dd[li]);
+    }
+    if (Fast && li == NS - 1 && NS > 1) return nearest;
+    return nearest && dd[li] < h.inf;
 }
 
 // The same question — "is sphere li the nearest thing the shadow ray hits?" (:420) — for pairwise DISJOINT spheres (host-proved,
@@ -502,13 +509,13 @@ __device__ __forceinline__ bool shadow_reaches_sphere(const HotSlab& h, v3 o, v3
 //    lies beyond it).
 // Sphere li is the nearest hit iff it yields a hit and no other sphere that yields a hit has a smaller b.  In exact arithmetic these are
 // the decisions of shadow_reaches_sphere; in fp32 they differ where a root lies within rounding of eps or a ray grazes a sphere.
-template <bool OccR2>   // OccR2: occ[i] holds |c_i - x|^2 - r_i^2
-__device__ __forceinline__ bool shadow_visible_disjoint(const HotSlab& h, v3 d, int li, const v3* xoc, const float* occ) {
+template <bool OccR2, int NS>   // OccR2: occ[i] holds |c_i - x|^2 - r_i^2
+__device__ __forceinline__ bool shadow_visible_disjoint(const HotSlabN<NS>& h, v3 d, int li, const v3* xoc, const float* occ) {
     MC_PT_DECISION_FP
-    float b[3];
-    bool hit[3];
+    float b[NS];
+    bool hit[NS];
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < NS; i++) {
         b[i] = dot(xoc[i], d);                                               // :318
         const float det = OccR2 ? b[i] * b[i] - occ[i] : (b[i] * b[i] - occ[i]) + h.r2[i];
         // (the ray is aimed INTO the light's cone, :408-:413: its line meets the light by construction and the root :319-:327 keep lies
@@ -519,7 +526,7 @@ __device__ __forceinline__ bool shadow_visible_disjoint(const HotSlab& h, v3 d, 
     }
     bool vis = hit[li];
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+    for (int i = 0; i < NS; i++)
         if (i != li) vis = vis && !(hit[i] && b[i] < b[li]);
     return vis;
 }
@@ -814,11 +821,15 @@ __device__ __forceinline__ v3 specular_bounce_general(int mat, v3 rd, v3 n, v3 n
     return rd;
 }
 
+// Spheres of the slab kernels' VGPR-resident scene copy (1 for the generic kernels, which have none).
+template <bool Slab, int NS> constexpr int slab_spheres() { return Slab && NS > 0 ? NS : 1; }
+
 // One sample: returns accrad (pathTracer.comp:356-449).  Box (fast math, slab scenes with SceneArgs::box_ok): see above.
 template <bool Fast, int NP, int NS, bool Slab, int Prec, bool Box = false>
 __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restrict__ lds_obj,
-                                           const uint32_t* __restrict__ lds_emissive, const HotSlab& hot, uint32_t gx, uint32_t gy,
-                                           uint32_t samp, WaveTime& wt) {
+                                           const uint32_t* __restrict__ lds_emissive, const HotSlabN<slab_spheres<Slab, NS>()>& hot,
+                                           uint32_t gx, uint32_t gy, uint32_t samp, WaveTime& wt) {
+    constexpr int HS = slab_spheres<Slab, NS>();
     const SceneArgs& sc = a.scene;
     constexpr bool LdsScene = NP < 0;
     const float* __restrict__ uobj = LdsScene ? lds_obj : sc.obj;   // records read with wave-uniform indices
@@ -833,16 +844,18 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
     // depth is the one formed at x in this one: once per bounce instead of twice (same operations, same operands).
     // The slab kernels' loop is rotated: the intersection of depth k + 1 is computed at the end of depth k, where c_i - x is still
     // in registers, so those nine subtractions are made once per bounce too.
-    float occ[3] = {0.0f, 0.0f, 0.0f};
+    float occ[HS];
+#pragma unroll
+    for (int i = 0; i < HS; i++) occ[i] = 0.0f;
     float t = 0.0f;
     int id = -1;
     static_assert(!Box || (Fast && Slab), "the closed-box specialisation is a fast-math slab kernel");
     MC_REGION(0);   // ray generation done
     if constexpr (Slab) {
         MC_REGION(1);   // primary intersect (camera ray)
-        v3 oc0[3];
+        v3 oc0[HS];
 #pragma unroll
-        for (int i = 0; i < 3; i++) { oc0[i] = v3{a.cam_oc[i][0], a.cam_oc[i][1], a.cam_oc[i][2]}; occ[i] = a.cam_occ[i]; }
+        for (int i = 0; i < HS; i++) { oc0[i] = v3{a.cam_oc[i][0], a.cam_oc[i][1], a.cam_oc[i][2]}; occ[i] = a.cam_occ[i]; }
         if (a.max_depth != 0u) id = intersect_slab<Fast, Box>(hot, ro, rd, t, false, occ, oc0);   // (Box: closed-box form, see intersect_slab)
     }
     MC_WT(7);   // ray generation + the camera ray's intersection
@@ -854,10 +867,10 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
         if (id < 0) break;   // :369 `continue` with an unchanged ray misses again at every later depth: no effect
         MC_REGION(2);   // bounce prologue
         v3 x = ro + rd * t;                                               // :374 (o + t*d: fp32 mul is commutative)
-        v3 xoc[3];                                                        // c_i - x (:317 at the next depth, :408 now)
+        v3 xoc[HS];                                                       // c_i - x (:317 at the next depth, :408 now)
         if constexpr (Slab) {
 #pragma unroll
-            for (int i = 0; i < 3; i++) { xoc[i] = v3{hot.c[i][0], hot.c[i][1], hot.c[i][2]} - x; occ[i] = dot(xoc[i], xoc[i]); }
+            for (int i = 0; i < HS; i++) { xoc[i] = v3{hot.c[i][0], hot.c[i][1], hot.c[i][2]} - x; occ[i] = dot(xoc[i], xoc[i]); }
         }
         const float* obj = lds_obj + 12 * id;                             // per-lane fetch from LDS
         const bool is_sphere = id >= np;
@@ -907,7 +920,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             v3 accmat_over_pi{0.0f, 0.0f, 0.0f};
             if constexpr (!Fast) accmat_over_pi = divs_recip<Fast>(accmat, kPi, kInvPi);
 #pragma unroll
-            for (int k = 0; k < (Slab ? 3 : n_lights); k++) {             // :403 (slab: unrolled, the index is a constant)
+            for (int k = 0; k < (Slab ? HS : n_lights); k++) {            // :403 (slab: unrolled, the index is a constant)
                 int i = k;
                 if (LdsScene) i = (int)lds_emissive[k];                   // host-built list of the spheres passing :407
                 else if (!((sc.emissive_mask >> i) & 1u)) continue;       // :407 (uniform)
@@ -917,8 +930,8 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 if constexpr (Slab) { lr2 = hot.r2[i]; lc = v3{hot.c[i][0], hot.c[i][1], hot.c[i][2]}; }   // the VGPR copies
                 else { lr2 = LdsScene ? ls[3] * ls[3] : sc.r2[i]; lc = v3{ls[0], ls[1], ls[2]}; }
                 v3 le{ls[4], ls[5], ls[6]};
-                v3 xc = Slab ? xoc[i] : lc - x;                           // :408
-                const float xcc = Slab ? occ[i] : dot(xc, xc);
+                v3 xc = Slab ? xoc[Slab ? i : 0] : lc - x;                // :408
+                const float xcc = Slab ? occ[Slab ? i : 0] : dot(xc, xc);
                 float cos_a_max;
                 v3 l = light_sample_direction<Fast>(xc, xcc, lr2, rnd, cos_a_max);   // :409-:413
                 float tne;
@@ -972,7 +985,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 MC_REGION(1);
                 if (!Box && !sc.materials_known) {   // (uniform, cold) an unknown material kept its ray: c_i - o must follow ro, not x
 #pragma unroll
-                    for (int i = 0; i < 3; i++) { xoc[i] = v3{hot.c[i][0], hot.c[i][1], hot.c[i][2]} - ro; occ[i] = dot(xoc[i], xoc[i]); }
+                    for (int i = 0; i < HS; i++) { xoc[i] = v3{hot.c[i][0], hot.c[i][1], hot.c[i][2]} - ro; occ[i] = dot(xoc[i], xoc[i]); }
                 }
                 id = intersect_slab<Fast, Box>(hot, ro, rd, t, false, occ, xoc);
             }
@@ -1049,7 +1062,7 @@ __global__ void __launch_bounds__(256, Fast ? 6 : 5) pathtrace_kernel(PTArgs a) 
         if (c.valid) acc = a.out[c.idx];
     }
     const float fspp = (float)a.spp;
-    HotSlab hot;
+    HotSlabN<slab_spheres<Slab, NS>()> hot;
     if constexpr (Slab) hot.load(a.scene);
     for (uint32_t base = a.sample_begin; base < a.sample_end; base += (uint32_t)S) {
         const LaneCoords c = lane_coords();
@@ -1119,9 +1132,6 @@ template <bool Fast, int NP, int NS, bool Slab, int S, int Prec, bool Box = fals
 inline int launch_one(const PTArgs& a, uint32_t tile_rows, hipStream_t s) {
     dim3 grid((a.W + block_w<S>() - 1u) / block_w<S>(), (tile_rows + block_h<S>() - 1u) / block_h<S>());
     size_t lds = NP == -2 ? 0u : scene_lds_bytes(a);
-#ifdef MC_PT_DIAG_LDS_PAD   // diagnostic build only (make variants): pad the dynamic LDS to cap the resident waves per CU
-    if (const char* e = std::getenv("MC_PT_LDS_PAD")) lds += (size_t)std::atoi(e);
-#endif
     auto kern = pathtrace_kernel<Fast, NP, NS, Slab, S, Prec, Box>;
     if (lds > 48u * 1024u) {   // beyond the default dynamic-LDS window: opt in (gfx950 has 160 KB per CU)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1134,22 +1144,39 @@ inline int launch_one(const PTArgs& a, uint32_t tile_rows, hipStream_t s) {
     return MC_OK;
 }
 
+// The slab kernels (6 axis-aligned planes + NS spheres, NS = 1 .. kMaxSlabSpheres: one instantiation per count, the sphere loops
+// unrolled over VGPR-resident centres) at width S.
+template <bool Fast, bool Box, int NS>
+inline int launch_slab_width(const PTArgs& a, int S, uint32_t tile_rows, hipStream_t s) {
+    if (S == 1) return launch_one<Fast, 6, NS, true, 1, 0, Box>(a, tile_rows, s);
+    if (S == 4) return launch_one<Fast, 6, NS, true, 4, 0, Box>(a, tile_rows, s);
+    if (S == 16) return launch_one<Fast, 6, NS, true, 16, 0, Box>(a, tile_rows, s);
+    return MC_ERR_INVALID_ARGUMENT;
+}
+template <bool Fast, bool Box>
+inline int launch_slab(const PTArgs& a, int S, uint32_t tile_rows, hipStream_t s) {
+    switch (a.scene.n_spheres) {
+        case 1: return launch_slab_width<Fast, Box, 1>(a, S, tile_rows, s);
+        case 2: return launch_slab_width<Fast, Box, 2>(a, S, tile_rows, s);
+        case 3: return launch_slab_width<Fast, Box, 3>(a, S, tile_rows, s);
+        case 4: return launch_slab_width<Fast, Box, 4>(a, S, tile_rows, s);
+        case 5: return launch_slab_width<Fast, Box, 5>(a, S, tile_rows, s);
+        case 6: return launch_slab_width<Fast, Box, 6>(a, S, tile_rows, s);
+        case 7: return launch_slab_width<Fast, Box, 7>(a, S, tile_rows, s);
+        case 8: return launch_slab_width<Fast, Box, 8>(a, S, tile_rows, s);
+        default: return MC_ERR_INVALID_ARGUMENT;
+    }
+}
+
 template <bool Fast>
 inline int launch_impl(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s) {
     if (prec == 0) {
         if constexpr (Fast) {
-            if (variant == 3) {
-                if (S == 1) return launch_one<Fast, 6, 3, true, 1, 0, true>(a, tile_rows, s);
-                if (S == 4) return launch_one<Fast, 6, 3, true, 4, 0, true>(a, tile_rows, s);
-                if (S == 16) return launch_one<Fast, 6, 3, true, 16, 0, true>(a, tile_rows, s);
-                return MC_ERR_INVALID_ARGUMENT;
-            }
+            if (variant == 3) return launch_slab<Fast, true>(a, S, tile_rows, s);
         }
         if (variant == 3) return MC_ERR_INVALID_ARGUMENT;
         if (variant == 1) {
-            if (S == 1) return launch_one<Fast, 6, 3, true, 1, 0>(a, tile_rows, s);
-            if (S == 4) return launch_one<Fast, 6, 3, true, 4, 0>(a, tile_rows, s);
-            if (S == 16) return launch_one<Fast, 6, 3, true, 16, 0>(a, tile_rows, s);
+            return launch_slab<Fast, false>(a, S, tile_rows, s);
         } else if (variant == 5) {   // generic, scene read from memory
             if (S == 1) return launch_one<Fast, -2, -2, false, 1, 0>(a, tile_rows, s);
             if (S == 4) return launch_one<Fast, -2, -2, false, 4, 0>(a, tile_rows, s);

@@ -38,6 +38,9 @@
 #ifndef MC_PT_POOL_WAVES
 #define MC_PT_POOL_WAVES 7   // waves per SIMD the register budget is set for (72 VGPRs; 6: 18.29 ms, 7: 18.11, 8: 18.68 at K2)
 #endif
+#ifndef MC_PT_POOL_STRICT_WAVES
+#define MC_PT_POOL_STRICT_WAVES 5   // strict kernel: 95 VGPRs
+#endif
 #ifndef MC_PT_POOL_KEEP_VALID   // the pixel's validity kept across the loop (a lane mask) instead of re-derived per batch
 #define MC_PT_POOL_KEEP_VALID 1
 #endif
@@ -56,15 +59,21 @@ namespace pt {
 
 constexpr uint32_t kPoolEntryFloats = 8;     // {rd.x, rd.y, rd.z, t | id (-1: nothing to trace), key0 = samp * maxDepth, rnd.x, rnd.y of key0}
 constexpr uint32_t kPoolRecordStride = 16;   // floats per staged record: {geo.xyz, p (fast: 1 / p) | colour.rgb, material + 256 * emits | emission.xyz, RN(1 / p) (fast: p) | fast: colour.rgb / p, the same integer bits}
-constexpr uint32_t kPoolRecordFloats = 9u * kPoolRecordStride;
+template <int NS> constexpr uint32_t pool_record_floats() { return (6u + (uint32_t)NS) * kPoolRecordStride; }   // 6 planes + NS spheres
 constexpr uint32_t kPoolStashFloats = 128u * kPoolEntryFloats;     // per wave: 64/S pixels x 2 batches x S entries
 constexpr uint32_t kPoolResultBatches = 4;                         // strict: result ring of 4 batches per pixel, 3 planes (x, y, z)
 constexpr uint32_t kPoolResultFloats = 64u * kPoolResultBatches * 3u;   // per wave: 64/S pixels x 4 batches x S samples x 3
 template <bool Fast> constexpr uint32_t pool_wave_lds_floats() { return kPoolStashFloats + (Fast ? 0u : kPoolResultFloats); }
-template <bool Fast> constexpr size_t pool_block_lds_bytes() { return (kPoolRecordFloats + 4u * pool_wave_lds_floats<Fast>()) * sizeof(float); }
+template <bool Fast, int NS> constexpr size_t pool_block_lds_bytes() { return (pool_record_floats<NS>() + 4u * pool_wave_lds_floats<Fast>()) * sizeof(float); }
+// Waves per SIMD the register budget is set for: 7 / 5 for the reference's three spheres (72 / 95 VGPRs); every further sphere
+// keeps five more values live across a bounce (c_i - x, |c_i - x|^2 and its r^2-reduced form), so the budget widens with the count.
+template <bool Fast, int NS> constexpr int pool_waves() {
+    return Fast ? (NS <= 3 ? MC_PT_POOL_WAVES : NS <= 5 ? 6 : 5) : (NS <= 3 ? MC_PT_POOL_STRICT_WAVES : 4);
+}
 
-template <bool Fast, int S>
-__global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_pool_kernel(PTArgs a) {
+template <bool Fast, int S, int NS>
+__global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_kernel(PTArgs a) {
+    constexpr uint32_t kPoolRecordFloats = pool_record_floats<NS>();
     extern __shared__ float lds_dyn[];
     float* lds_obj = lds_dyn;
     // The 9 records, re-packed for two 16-byte reads per bounce at address id << 6: the plane normal / sphere centre with the
@@ -73,7 +82,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
     // Fast math: slot 3 holds v_rcp_f32(p), the factor :397's division multiplies by — formed once per block instead of once
     // per bounce and lane (a transcendental blocks the SIMD for 8 cycles); p itself, which :396 compares with, is in slot 11.
     // Strict: slot 3 holds p and slot 11 the correctly rounded 1 / p that the short division of :397 starts from (dm::div3).
-    if (threadIdx.x < 9u) {
+    if (threadIdx.x < 6u + (uint32_t)NS) {
         const float* o = a.scene.obj + 12u * threadIdx.x;
         float* r = lds_obj + kPoolRecordStride * threadIdx.x;
         const float p = dm::gmax(dm::gmax(o[8], o[9]), o[10]);
@@ -90,8 +99,8 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
     // |c_i - x|^2 - r_i^2, formed once, instead of each adding r_i^2 to its b^2 - |c_i - x|^2
     constexpr bool kOccR2 = Fast && MC_PT_FAST_OCC_MINUS_R2;
     constexpr uint32_t TW = WaveTile<S>::w, TH = WaveTile<S>::h, Ring = 2u * (uint32_t)S, RRing = kPoolResultBatches * (uint32_t)S;
-    HotSlab hot;
-    hot.load<MC_PT_POOL_HOT_VGPR, MC_PT_POOL_HOT_W>(a.scene);   // (uniform operands: this kernel has no vector registers to spare for copies)
+    HotSlabN<NS> hot;
+    hot.template load<MC_PT_POOL_HOT_VGPR, MC_PT_POOL_HOT_W>(a.scene);   // (uniform operands: this kernel has no vector registers to spare for copies)
     // A lane's pixel (pix = lane / S of the wave tile) and slot of a batch (sub = lane % S) never change.  What derives from them
     // and is needed only now and then — the stash base, the tile row, the validity — is derived afresh from an opaque copy of
     // the thread id where it is used, so that it does not occupy registers across the bounce loop (80 VGPRs = 6 waves per SIMD).
@@ -143,7 +152,9 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
     uint32_t cur = 0u;        // strict: index (within my pixel) of the sample this lane traces; its result slot is cur % RRing
     uint32_t committed = 0u;  // strict: samples of my pixel already added to acc (the same value in all S lanes)
     const float fspp = (float)a.spp;
-    float emissive = 1.0f, t = 0.0f, occ[3] = {0.0f, 0.0f, 0.0f};
+    float emissive = 1.0f, t = 0.0f, occ[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) occ[i] = 0.0f;
     int id = 0;
     uint32_t key = 0u, kend = 0u, krr = 0u;   // key0 + depth; key0 + maxDepth; key0 + 5 (:395: roulette while key > krr)
     // rand01 of the bounce about to be traced (:393).  It is drawn at the END of the previous bounce, together with the Russian
@@ -195,10 +206,10 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                 const Lane g = my_lane(MC_PT_POOL_KEEP_VALID ? false : true);
                 const uint32_t samp = a.sample_begin + batch * (uint32_t)S + g.sub;
                 const v3 crd = camera_ray<Fast>(a, gx, gy, samp);
-                v3 oc0[3];
-                float occ0[3], ct;
+                v3 oc0[NS];
+                float occ0[NS], ct;
 #pragma unroll
-                for (int i = 0; i < 3; i++) {
+                for (int i = 0; i < NS; i++) {
                     oc0[i] = v3{a.cam_oc[i][0], a.cam_oc[i][1], a.cam_oc[i][2]};
                     occ0[i] = kOccR2 ? a.cam_occ[i] - hot.r2[i] : a.cam_occ[i];
                 }
@@ -241,12 +252,12 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
             {
                 MC_REGION(4);    // a bounce: prologue
                 v3 x = ro + rd * t;                                               // :374
-                v3 xoc[3];                                                        // c_i - x (:317 at the next depth, :408 now)
+                v3 xoc[NS];                                                       // c_i - x (:317 at the next depth, :408 now)
 #pragma unroll
-                for (int i = 0; i < 3; i++) { xoc[i] = v3{hot.c[i][0], hot.c[i][1], hot.c[i][2]} - x; occ[i] = dot(xoc[i], xoc[i]); }
-                float xcc[3];                                                     // |c_i - x|^2 itself (:410 needs it)
+                for (int i = 0; i < NS; i++) { xoc[i] = v3{hot.c[i][0], hot.c[i][1], hot.c[i][2]} - x; occ[i] = dot(xoc[i], xoc[i]); }
+                float xcc[NS];                                                    // |c_i - x|^2 itself (:410 needs it)
 #pragma unroll
-                for (int i = 0; i < 3; i++) { xcc[i] = occ[i]; if constexpr (kOccR2) occ[i] = occ[i] - hot.r2[i]; }
+                for (int i = 0; i < NS; i++) { xcc[i] = occ[i]; if constexpr (kOccR2) occ[i] = occ[i] - hot.r2[i]; }
                 const float4* obj = reinterpret_cast<const float4*>(lds_obj + kPoolRecordStride * (uint32_t)id);   // per-lane fetch
                 // (fast: past depth 5 the colour row is the one already divided by the roulette probability)
                 const float4 o0 = obj[0], o1 = obj[(Fast && MC_PT_FAST_COLOUR_OVER_P && key > krr) ? 3 : 1];
@@ -286,7 +297,7 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
                     v3 accmat_over_pi{0.0f, 0.0f, 0.0f};                          // strict: :422's accmat / pi, once per bounce
                     if constexpr (!Fast) accmat_over_pi = divs_recip<Fast>(accmat, kPi, kInvPi);
 #pragma unroll
-                    for (int i = 0; i < 3; i++) {                                 // :403
+                    for (int i = 0; i < NS; i++) {                                // :403
                         if (!((a.scene.emissive_mask >> i) & 1u)) continue;       // :407 (uniform)
                         const float* ls = a.scene.obj + 12 * (6 + i);
                         v3 le{ls[4], ls[5], ls[6]};
@@ -363,6 +374,13 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
             sum.x += from_lane(acc.x, src); sum.y += from_lane(acc.y, src); sum.z += from_lane(acc.z, src);
         }
         sum.x *= a.inv_spp; sum.y *= a.inv_spp; sum.z *= a.inv_spp;
+        // a later sample range of a progressive render (the samps.x protocol, :451-:452): the range's share is added to the stored
+        // accumulator.  (Fast math has no ordered-sum contract: 5 ranges and one launch agree within the tolerance, not bit for bit;
+        // the SAME split composes identically on every tiling.)
+        if (a.sample_begin > 0u && fin.valid) {
+            const float4 prev = a.out[(size_t)fin.ty * a.W + gx];
+            sum.x += prev.x; sum.y += prev.y; sum.z += prev.z;
+        }
     } else {
         // ---- every sample of the pool has ended: the batches not yet added, in sample order (entries beyond the sample range hold zeros)
         while (committed < n_batches * (uint32_t)S) {
@@ -382,15 +400,27 @@ __global__ void __launch_bounds__(256, Fast ? MC_PT_POOL_WAVES : 5) pathtrace_po
     if (fin.valid && fin.sub == 0u) a.out[(size_t)fin.ty * a.W + gx] = sum;
 }
 
-template <bool Fast, int S> inline int launch_pool_one(const PTArgs& a, uint32_t tile_rows, hipStream_t s) {
+template <bool Fast, int S, int NS> inline int launch_pool_one(const PTArgs& a, uint32_t tile_rows, hipStream_t s) {
     dim3 grid((a.W + block_w<S>() - 1u) / block_w<S>(), (tile_rows + block_h<S>() - 1u) / block_h<S>());
-    hipLaunchKernelGGL((pathtrace_pool_kernel<Fast, S>), grid, dim3(256), pool_block_lds_bytes<Fast>(), s, a);
+    constexpr size_t lds = pool_block_lds_bytes<Fast, NS>();
+    hipLaunchKernelGGL((pathtrace_pool_kernel<Fast, S, NS>), grid, dim3(256), lds, s, a);
     return MC_OK;
 }
-// variant 4 of launch_fast / launch_strict: 16 lanes per pixel and batch (the host never passes anything else)
+// variant 4 of launch_fast / launch_strict: 16 lanes per pixel and batch (the host never passes anything else); one instantiation
+// per sphere count 1 .. kMaxSlabSpheres
 template <bool Fast> inline int launch_pool(const PTArgs& a, int S, uint32_t tile_rows, hipStream_t s) {
-    if (S == 16) return launch_pool_one<Fast, 16>(a, tile_rows, s);
-    return MC_ERR_INVALID_ARGUMENT;
+    if (S != 16) return MC_ERR_INVALID_ARGUMENT;
+    switch (a.scene.n_spheres) {
+        case 1: return launch_pool_one<Fast, 16, 1>(a, tile_rows, s);
+        case 2: return launch_pool_one<Fast, 16, 2>(a, tile_rows, s);
+        case 3: return launch_pool_one<Fast, 16, 3>(a, tile_rows, s);
+        case 4: return launch_pool_one<Fast, 16, 4>(a, tile_rows, s);
+        case 5: return launch_pool_one<Fast, 16, 5>(a, tile_rows, s);
+        case 6: return launch_pool_one<Fast, 16, 6>(a, tile_rows, s);
+        case 7: return launch_pool_one<Fast, 16, 7>(a, tile_rows, s);
+        case 8: return launch_pool_one<Fast, 16, 8>(a, tile_rows, s);
+        default: return MC_ERR_INVALID_ARGUMENT;
+    }
 }
 
 }  // namespace pt
