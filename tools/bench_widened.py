@@ -38,7 +38,9 @@ def room(rng, n_spheres, n_lights):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--only", default="", help="comma-separated rows to run (f2,f3,f4,f4box); default all")
     a = ap.parse_args()
+    only = set(x for x in a.only.split(",") if x)
     B, O = entry.load_package().bindings, entry.load_oracle()
     ctx = B.Context(0)
     st = torch.cuda.Stream()
@@ -77,7 +79,7 @@ def main():
     # ---- (f)2: the sphere-walled scene of TEST_PRECISION_WITH_LARGE_SPHERE_WALLS through the extended-precision sphere tests
     LP, LS = O.LARGE_SPHERE_PLANES, O.LARGE_SPHERE_SPHERES
     spp = 100
-    for prec, pname in ((B.PT_PREC_F32, "fp32 (the reference's default build)"), (B.PT_PREC_FP64, "native fp64 (:132-143)"),
+    for prec, pname in () if only and "f2" not in only else ((B.PT_PREC_F32, "fp32 (the reference's default build)"), (B.PT_PREC_FP64, "native fp64 (:132-143)"),
                         (B.PT_PREC_DS, "DS_f32_f32 (:144-213)"), (B.PT_PREC_DF64, "DF64_F32_F32 (:214-256)")):
         for mode, mname in ((B.PT_MATH_STRICT, "strict"), (B.PT_MATH_FAST, "fast")):
             p = B.pathtrace_params(W, H, spp, math_mode=mode, flags=B.pt_precision(prec))
@@ -88,26 +90,49 @@ def main():
             emit("f2", f"sphere-walled scene, sphere test {pname}, {mname}", spp, ms,
                  "1 plane + 9 spheres (six of radius 1e5): generic kernel with the run-time precision switch",
                  c[0] if c else None, f"oracle on the host cores, 2 samples x 64 rows ({c[1]:.1f} s)" if c else None)
-    # ---- (f)3: progressive sample ranges (the samps.x protocol), K2 scene, strict
+    # ---- (f)3: progressive sample ranges (the samps.x protocol), K2 scene, both math modes (fast ranges run the pool kernel since round 4)
     spp = 500
-    whole = B.pathtrace_params(W, H, spp)
-    ms_whole = timed(lambda: ctx.pathtrace_device(whole, buf.data_ptr(), stream=s))
-    emit("f3", "K2 strict, one launch", spp, ms_whole, "strict sample-pool kernel")
-    for parts in (5, 25):
-        cuts = [round(i * spp / parts) for i in range(parts + 1)]
-        ps = [B.pathtrace_params(W, H, spp, sample_begin=b, sample_end=e) for b, e in zip(cuts[:-1], cuts[1:])]
+    for mode, mname in () if only and "f3" not in only else ((B.PT_MATH_STRICT, "strict"), (B.PT_MATH_FAST, "fast")):
+        whole = B.pathtrace_params(W, H, spp, math_mode=mode)
+        ms_whole = timed(lambda: ctx.pathtrace_device(whole, buf.data_ptr(), stream=s))
+        emit("f3", f"K2 {mname}, one launch", spp, ms_whole, f"{mname} sample-pool kernel")
+        for parts in (5, 25):
+            cuts = [round(i * spp / parts) for i in range(parts + 1)]
+            ps = [B.pathtrace_params(W, H, spp, math_mode=mode, sample_begin=b, sample_end=e) for b, e in zip(cuts[:-1], cuts[1:])]
+            assert all(B.pathtrace_select_kernel(q).kernel == B.PT_KERNEL_POOL for q in ps)
 
-        def run():
-            for q in ps:
-                ctx.pathtrace_device(q, buf.data_ptr(), stream=s)
-        ms = timed(run)
-        emit("f3", f"K2 strict in {parts} ranges of {spp // parts} samples (accumulator continued in the buffer)", spp, ms,
-             f"strict sample-pool kernel per range; {ms / ms_whole:.3f} x the one-launch time")
+            def run():
+                for q in ps:
+                    ctx.pathtrace_device(q, buf.data_ptr(), stream=s)
+            ms = timed(run)
+            emit("f3", f"K2 {mname} in {parts} ranges of {spp // parts} samples (accumulator continued in the buffer)", spp, ms,
+                 f"{mname} sample-pool kernel per range; {ms / ms_whole:.3f} x the one-launch time")
+    # ---- (f)4, the specialised kernels beyond three spheres (round 4): the reference box with 1 .. 8 disjoint spheres takes the
+    # slab / closed-box / sample-pool kernels instantiated per sphere count; beside each the GENERIC kernel on the same scene
+    if not only or "f4box" in only:
+        from test_gpu_scenes import box_scene
+        spp = 100
+        base = {}
+        for ns, lights in ((3, 1), (1, 1), (2, 1), (4, 1), (5, 1), (5, 2), (8, 1)):
+            if ns == 3:
+                planes, spheres = O.DEFAULT_PLANES.copy().reshape(6, 12), O.DEFAULT_SPHERES.copy().reshape(3, 12)
+            else:
+                planes, spheres = box_scene(O, ns, np.random.default_rng(40 + 10 * ns + lights), lights)
+            for mode, mname in ((B.PT_MATH_STRICT, "strict"), (B.PT_MATH_FAST, "fast")):
+                p = B.pathtrace_params(W, H, spp, math_mode=mode)
+                assert B.pathtrace_select_kernel(p, planes, spheres).kernel == B.PT_KERNEL_POOL
+                ms = timed(lambda: ctx.pathtrace_device(p, buf.data_ptr(), planes=planes, spheres=spheres, stream=s))
+                g = B.pathtrace_params(W, H, spp, math_mode=mode, flags=B.PT_GENERIC_KERNEL)
+                ms_g = timed(lambda: ctx.pathtrace_device(g, buf.data_ptr(), planes=planes, spheres=spheres, stream=s))
+                if ns == 3:
+                    base[mname] = ms
+                emit("f4box", f"the box with {ns} spheres ({lights} light{'s' if lights > 1 else ''}), {mname}: sample-pool kernel", spp, ms,
+                     f"{ms / base[mname]:.2f} x the reference scene's (3 spheres) time; the generic kernel on the same scene: {ms_g:.3f} ms ({ms_g / ms:.2f} x)")
     # ---- (f)4: general scenes through the generic (LDS-resident scene) kernel
     rng = np.random.default_rng(5)
     spp = 100
     DP, DS = O.DEFAULT_PLANES.copy().reshape(6, 12), O.DEFAULT_SPHERES.copy().reshape(3, 12)
-    for name, planes, spheres in (("the default scene with its planes permuted (generic kernel on K2's geometry)", DP[[2, 3, 0, 1, 4, 5]], DS),
+    for name, planes, spheres in () if only and "f4" not in only else (("the default scene with its planes permuted (generic kernel on K2's geometry)", DP[[2, 3, 0, 1, 4, 5]], DS),
                                   ("6 planes + 64 spheres", *room(rng, 64, 3)), ("6 planes + 256 spheres", *room(rng, 256, 4)),
                                   ("6 planes + 512 spheres", *room(rng, 512, 5)), ("6 planes + 1500 spheres", *room(rng, 1500, 8)),
                                   ("6 planes + 6000 spheres (beyond the LDS store)", *room(rng, 6000, 8))):

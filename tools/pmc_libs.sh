@@ -20,7 +20,7 @@ rows = {}
 for lib in sys.argv[2:]:
     n = os.path.basename(lib)[:-3]
     agg = collections.defaultdict(list)
-    for f in glob.glob(f"{out}/{n}_*/*/*_counter_collection.csv"):
+    for f in glob.glob(f"{out}/{n}_[ab]/*/*_counter_collection.csv"):   # (_a / _b: the two counter passes of THIS library)
         for r in csv.DictReader(open(f)):
             if KERNEL.search(r["Kernel_Name"]):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))

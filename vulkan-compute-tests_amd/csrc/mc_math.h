@@ -61,7 +61,33 @@ __device__ __forceinline__ float div_step(float a, float s, float y) {
     return __builtin_fmaf(r, y, q0);
 }
 
+#ifdef MC_EXPERIMENT_NO_TRANS
+// MEASUREMENT BUILD ONLY (make exp EXP_FLAGS=-DMC_EXPERIMENT_NO_TRANS; tools/pmc_libs.sh): the fast kernels' hardware transcendentals
+// replaced by ordinary-instruction approximations (bit-pattern seeds + two Newton steps; a parabola pair for sin / cos) good to ~1e-3 —
+// the paths stay statistically the same, the image is NOT the product's.  Answers one question: what does the SIMD pay per VALU
+// instruction when no transcendental is in the stream (profiles/r04_no_trans_pmc.txt)?
+__device__ __forceinline__ float nt_rcp(float x) {
+    const float ax = __builtin_fabsf(x);
+    float r = as_float(0x7EF311C7u - as_uint(ax));
+    r = r * (2.0f - ax * r); r = r * (2.0f - ax * r);
+    return __builtin_copysignf(r, x);
+}
+__device__ __forceinline__ float nt_rsq(float x) {
+    float r = as_float(0x5F375A86u - (as_uint(x) >> 1));
+    const float h = 0.5f * x;
+    r = r * (1.5f - h * r * r); r = r * (1.5f - h * r * r);
+    return r;
+}
+__device__ __forceinline__ float nt_sin_rev(float u) {      // sin(2 pi u), u in revolutions
+    const float x = u - __builtin_rintf(u);                 // [-0.5, 0.5]
+    const float y = 8.0f * x * (1.0f - 2.0f * __builtin_fabsf(x));
+    return y * (0.775f + 0.225f * __builtin_fabsf(y));
+}
+#endif
 template <bool Fast> __device__ __forceinline__ float fdiv(float a, float b) {
+#ifdef MC_EXPERIMENT_NO_TRANS
+    if (Fast) return a * nt_rcp(b);
+#endif
     if (Fast) return a * __builtin_amdgcn_rcpf(b);
     return ieee_div(a, b);
 }
@@ -84,11 +110,17 @@ template <bool Fast, bool HaveY> __device__ __forceinline__ void div3(float& a0,
     a0 = fdiv<Fast>(a0, s); a1 = fdiv<Fast>(a1, s); a2 = fdiv<Fast>(a2, s);
 }
 template <bool Fast> __device__ __forceinline__ float fsqrt(float a) {
+#ifdef MC_EXPERIMENT_NO_TRANS
+    if (Fast) return a * nt_rsq(a);
+#endif
     if (Fast) return __builtin_amdgcn_sqrtf(a);
     if (__builtin_expect(wave_all(in_short_window(a)), 1)) return sqrt_short(a);
     return ieee_sqrt(a);
 }
 template <bool Fast> __device__ __forceinline__ float inversesqrt(float a) {
+#ifdef MC_EXPERIMENT_NO_TRANS
+    if (Fast) return nt_rsq(a);
+#endif
     if (Fast) return __builtin_amdgcn_rsqf(a);
     if (__builtin_expect(wave_all(in_short_window(a)), 1)) return rcp_short(sqrt_short(a));   // sqrt in [2^-50, 2^50): inside rcp_short's window
     return ieee_div(1.0f, ieee_sqrt(a));
@@ -144,6 +176,9 @@ __device__ __forceinline__ void mc_sincos(float x, float& s, float& c) {
 // sin/cos of angle = two_pi_f32 * u where `angle` is the already-rounded fp32 product the shader
 // computes (pathTracer.comp:412,426) and `u` the random number it came from.
 template <bool Fast> __device__ __forceinline__ void sincos_angle(float angle, float u, float& s, float& c) {
+#ifdef MC_EXPERIMENT_NO_TRANS
+    if (Fast) { s = nt_sin_rev(u); c = nt_sin_rev(u + 0.25f); return; }
+#endif
     if (Fast) {
         // v_sin_f32 / v_cos_f32 take revolutions: sin(2*pi*u).  u in [0,1].
         s = __builtin_amdgcn_sinf(u);

@@ -388,11 +388,14 @@ template <int NS> struct HotSlabN {
 // Closed (fast math, SceneArgs::box_ok, origin inside the box): the nearest facing plane IS a hit — the |d_a| > 1e-7 / t < 1e20
 // tests of :119 / :336 can only fail for a ray that runs along a wall it starts on to within 1e-7, or a NaN ray (which then
 // gathers nothing: every later comparison with its NaN t is false) — so they and the final "anything hit?" select are dropped.
-template <bool Fast, bool Closed = false, bool OccR2 = false, int StatsBase = -1, int NS = 3>   // OccR2: occ[i] holds |c_i - o|^2 - r_i^2 (fast math)
-__device__ __forceinline__ int intersect_slab(const HotSlabN<NS>& h, v3 o, v3 d, float& t_out, bool shadow_skip_planes,
-                                              const float* occ = nullptr,     // occ[i] = dot(c_i - o, c_i - o) and
-                                              const v3* oc_at_o = nullptr) {  // oc_at_o[i] = c_i - o if the caller has them
+// HaveOc: the caller passes c_i - o and its squared length (a COMPILE-TIME fact: a run-time "pointer given?" test on a private
+// array is not foldable on this target — address 0 is a valid stack address — and kept the 8-sphere array in scratch memory).
+template <bool Fast, bool Closed, bool OccR2, int StatsBase, bool HaveOc, int NS>   // OccR2: occ[i] holds |c_i - o|^2 - r_i^2 (fast math)
+__device__ __forceinline__ int intersect_slab_impl(const HotSlabN<NS>& h, v3 o, v3 d, float& t_out, bool shadow_skip_planes,
+                                                   const float* occ,       // occ[i] = dot(c_i - o, c_i - o) and
+                                                   const v3* oc_at_o) {    // oc_at_o[i] = c_i - o if the caller has them
     MC_PT_DECISION_FP
+    static_assert(HaveOc || !OccR2, "the r^2-reduced squared lengths come from the caller");
     float t = h.inf;
     int id = -1;
     if (Fast && MC_PT_FAST_PLANES_ONE_RCP && !shadow_skip_planes) {
@@ -439,9 +442,12 @@ __device__ __forceinline__ int intersect_slab(const HotSlabN<NS>& h, v3 o, v3 d,
     // per-sphere blocks are skipped for the whole wave more often than the merged one, and the selects are paid by every lane.)
 #pragma unroll
     for (int i = 0; i < NS; i++) {
-        v3 oc = oc_at_o ? oc_at_o[i] : v3{h.c[i][0], h.c[i][1], h.c[i][2]} - o;   // :317
+        v3 oc;                                                               // :317
+        if constexpr (HaveOc) oc = oc_at_o[i]; else oc = v3{h.c[i][0], h.c[i][1], h.c[i][2]} - o;
         float b = dot(oc, d);                                                // :318
-        float det = OccR2 ? b * b - occ[i] : (b * b - (occ ? occ[i] : dot(oc, oc))) + h.r2[i];
+        float occ_i;
+        if constexpr (HaveOc) occ_i = occ[i]; else occ_i = dot(oc, oc);
+        float det = OccR2 ? b * b - occ_i : (b * b - occ_i) + h.r2[i];
         if (!(det < 0.0f)) {                                                 // :319
             if constexpr (StatsBase >= 0) MC_REGION(StatsBase + i);          // (diagnostic build: root block of sphere i)
             float sq = dm::fsqrt<Fast>(det);
@@ -456,6 +462,15 @@ __device__ __forceinline__ int intersect_slab(const HotSlabN<NS>& h, v3 o, v3 d,
     t_out = t;
     if constexpr (Closed) return id;
     return (t < h.inf) ? id : -1;                                            // :336
+}
+template <bool Fast, bool Closed = false, bool OccR2 = false, int StatsBase = -1, int NS = 3>
+__device__ __forceinline__ int intersect_slab(const HotSlabN<NS>& h, v3 o, v3 d, float& t_out, bool shadow_skip_planes) {
+    return intersect_slab_impl<Fast, Closed, OccR2, StatsBase, false, NS>(h, o, d, t_out, shadow_skip_planes, nullptr, nullptr);
+}
+template <bool Fast, bool Closed = false, bool OccR2 = false, int StatsBase = -1, int NS = 3>
+__device__ __forceinline__ int intersect_slab(const HotSlabN<NS>& h, v3 o, v3 d, float& t_out, bool shadow_skip_planes,
+                                              const float* occ, const v3* oc_at_o) {
+    return intersect_slab_impl<Fast, Closed, OccR2, StatsBase, true, NS>(h, o, d, t_out, shadow_skip_planes, occ, oc_at_o);
 }
 
 // Shadow ray of next-event estimation against the three spheres only (slab scenes whose walls can never win, see
@@ -1006,8 +1021,14 @@ template <> struct WaveTile<64> { static constexpr uint32_t w = 1, h = 1; };
 template <int S> constexpr uint32_t block_w() { return 2u * WaveTile<S>::w; }
 template <int S> constexpr uint32_t block_h() { return 2u * WaveTile<S>::h; }
 
+// Waves per SIMD the register budget is set for: 6 / 5 (fast / strict) for the generic kernels and the reference's three spheres;
+// a slab scene with more spheres keeps five more values per sphere live across a bounce (and leaves its constants to the scalar file).
+template <bool Fast, bool Slab, int NS> constexpr int rounds_waves() {
+    return (!Slab || NS <= 3) ? (Fast ? 6 : 5) : NS <= 5 ? (Fast ? 5 : 4) : (Fast ? 4 : 3);
+}
+
 template <bool Fast, int NP, int NS, bool Slab, int S, int Prec, bool Box = false>
-__global__ void __launch_bounds__(256, Fast ? 6 : 5) pathtrace_kernel(PTArgs a) {
+__global__ void __launch_bounds__(256, (rounds_waves<Fast, Slab, NS>())) pathtrace_kernel(PTArgs a) {
     // dynamic LDS (no static __shared__ in front: the base stays 16-B aligned): [records | emissive list]
     extern __shared__ float lds_dyn[];
     float* lds_obj = lds_dyn;
@@ -1063,7 +1084,7 @@ __global__ void __launch_bounds__(256, Fast ? 6 : 5) pathtrace_kernel(PTArgs a) 
     }
     const float fspp = (float)a.spp;
     HotSlabN<slab_spheres<Slab, NS>()> hot;
-    if constexpr (Slab) hot.load(a.scene);
+    if constexpr (Slab) hot.template load<(NS <= 3)>(a.scene);   // (the 25 constants of 6 + 3 objects in VGPRs; larger scenes: SGPR operands)
     for (uint32_t base = a.sample_begin; base < a.sample_end; base += (uint32_t)S) {
         const LaneCoords c = lane_coords();
         const uint32_t s = base + c.j;

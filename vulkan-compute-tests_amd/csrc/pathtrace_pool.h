@@ -68,7 +68,7 @@ template <bool Fast, int NS> constexpr size_t pool_block_lds_bytes() { return (p
 // Waves per SIMD the register budget is set for: 7 / 5 for the reference's three spheres (72 / 95 VGPRs); every further sphere
 // keeps five more values live across a bounce (c_i - x, |c_i - x|^2 and its r^2-reduced form), so the budget widens with the count.
 template <bool Fast, int NS> constexpr int pool_waves() {
-    return Fast ? (NS <= 3 ? MC_PT_POOL_WAVES : NS <= 5 ? 6 : 5) : (NS <= 3 ? MC_PT_POOL_STRICT_WAVES : 4);
+    return Fast ? (NS <= 3 ? MC_PT_POOL_WAVES : NS <= 5 ? 6 : NS <= 6 ? 5 : 4) : (NS <= 3 ? MC_PT_POOL_STRICT_WAVES : NS <= 6 ? 4 : 3);
 }
 
 template <bool Fast, int S, int NS>
