@@ -378,10 +378,13 @@ def main():
         # The clock the kernel itself held, from the committed PMC pass of this configuration (GRBM_GUI_ACTIVE / 8 XCDs / duration).
         # NOT mc_context_measure_clock: that probe reads the clock under ITS OWN dense FMA chain — 2.15 GHz after a K3 step during
         # which the path tracer held 2.38 GHz (profiles/r04_k3_clock.txt) — and is kept only to compare boxes.
+        # (cycles of the profiled launch / the LIVE, unprofiled kernel time: a launch's cycle count is reproducible to < 1 %, while the
+        # profiled duration of a 14 ms kernel carries the counters' start / stop overhead)
         prof_entries, _ = profiled_summary(cfg_name, args, n)
         prof_ghz = None
-        for e in (prof_entries or {}).values():
-            prof_ghz = e.get("derived", {}).get("kernel_clock_ghz") or prof_ghz
+        if prof_entries and len(prof_entries) == 1:
+            cyc = next(iter(prof_entries.values())).get("derived", {}).get("gpu_cycles_per_xcd")
+            prof_ghz = cyc / (kernel_ms * 1e6) if cyc else None
         contracted = is_pt and args.math == "fast"
         if is_pt and args.math == "fast":
             note = ("fast math: hardware transcendentals, a*b+c contraction, identities of exact arithmetic not executed (toleranced "
@@ -409,7 +412,7 @@ def main():
                           if n > 1 else {}),
                        **({"exchange_async": bool(not ex.sync_mode and backend == "nccl")} if n > 1 else {}),
                        "device": dev_name, "compute_units": cus, "sclk_mhz_probe_kernel": round(sclk_mhz, 1),
-                       "sclk_note": "clock under the PROBE kernel's dense FMA chain (compares boxes); the timed kernel's own clock is roofline.kernel_clock_ghz_profiled",
+                       "sclk_note": "clock under the PROBE kernel's dense FMA chain (compares boxes); the timed kernel's own clock is roofline.kernel_clock_ghz",
                        **({"unit_note": "reference-equivalent pixel-iterations (see roofline.lane_ops.note)"} if not is_pt else {}),
                        **({"backend": backend, "world_size": dist.get_world_size(), "ranks": ranks_info,
                            "gather_ms_rank0": round(gather_ms, 4), "gather_bytes_per_rank": gather_bytes,
@@ -420,8 +423,8 @@ def main():
                        **({"verified_equal_to_single_gpu": verified} if verified is not None else {})},
             "roofline": {"bound": "valu", "kernel": kern, "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_TFLOPS,
-                         "kernel_clock_ghz_profiled": prof_ghz,
-                         **({"frac_at_profiled_clock": achieved_tflops * 1e12 / (2.0 * cus * 4 * 32 * prof_ghz * 1e9)} if prof_ghz else {}),
+                         "kernel_clock_ghz": prof_ghz,   # GRBM_GUI_ACTIVE / 8 of the committed PMC pass / live kernel time
+                         **({"frac_at_kernel_clock": achieved_tflops * 1e12 / (2.0 * cus * 4 * 32 * prof_ghz * 1e9)} if prof_ghz else {}),
                          # executed fp32 lane-flops (committed PMC instruction mix) over the live kernel time
                          "executed": (exec_flops / (kernel_ms * 1e-3) / 1e12) if exec_flops else None,
                          "executed_frac": (exec_flops / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS) if exec_flops else None,

@@ -47,6 +47,28 @@ __device__ __forceinline__ float rcp_short(float b) {
     return __builtin_fmaf(e, r, r);
 }
 
+// inversesqrt(x) := RN(1 / RN(sqrt(x))) (two roundings: the definition above) with ONE transcendental: the correctly rounded root s as in
+// sqrt_short, then one Newton step on 1 / s seeded with the v_rsq_f32 value already at hand instead of a second seed from v_rcp_f32
+// (a transcendental costs 13 issue cycles among other instructions, profiles/r04_no_trans_pmc.txt).  The step lands on the correctly
+// rounded quotient everywhere in the window except where s = 2 - ulp (x = 4 - 1 ulp and 4 - 2 ulp of every second binade): there 1 / s =
+// 0.5 + 2^-25 + ... sits just above a round-to-even tie that no step from below leaves (profiles/r02_exact_math_exhaustive.txt, "rsq only,
+// 1 step on 1/s from y": exactly these two patterns per binade pair) — those two get their ulp added by an integer test on x's bits.
+// Established like the other short forms: EVERY fp32 pattern of the window compared with the IEEE expansion on the device
+// (tests/test_gpu_parity.py::test_short_forms_exhaustive, fn 5; profiles/r04_exact_rsqrt_one_trans.txt).
+#ifndef MC_MATH_RSQRT_ONE_TRANS
+#define MC_MATH_RSQRT_ONE_TRANS 1
+#endif
+__device__ __forceinline__ float rsqrt_short(float x) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = x * y;
+    const float d = __builtin_fmaf(-g, g, x);
+    const float s = __builtin_fmaf(d, 0.5f * y, g);           // = sqrt_short(x)
+    const float e = __builtin_fmaf(-s, y, 1.0f);
+    const float r = __builtin_fmaf(e, y, y);
+    const uint32_t tie = ((as_uint(x) & 0x00fffffeu) == 0x007ffffeu) ? 1u : 0u;   // even biased exponent, mantissa 0x7ffffe / 0x7fffff
+    return as_float(as_uint(r) + tie);
+}
+
 // Short division for numerators that share a positive divisor s (a colour divided by a probability, by pi, by the sample
 // count): with y = RN(1/s),  q0 = a*y; r = fma(-s, q0, a); q = fma(r, y, q0)  IS the correctly rounded a/s for every pair of
 // normal operands while nothing over- or underflows — all 2^23 x 2^23 mantissa pairs enumerated against the IEEE expansion,
@@ -122,7 +144,8 @@ template <bool Fast> __device__ __forceinline__ float inversesqrt(float a) {
     if (Fast) return nt_rsq(a);
 #endif
     if (Fast) return __builtin_amdgcn_rsqf(a);
-    if (__builtin_expect(wave_all(in_short_window(a)), 1)) return rcp_short(sqrt_short(a));   // sqrt in [2^-50, 2^50): inside rcp_short's window
+    if (__builtin_expect(wave_all(in_short_window(a)), 1))
+        return MC_MATH_RSQRT_ONE_TRANS ? rsqrt_short(a) : rcp_short(sqrt_short(a));   // (sqrt in [2^-50, 2^50): inside rcp_short's window)
     return ieee_div(1.0f, ieee_sqrt(a));
 }
 
