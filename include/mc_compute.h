@@ -183,13 +183,13 @@ int mc_pathtrace_render_rgba8(mc_context* ctx, const mc_pathtrace_params* p, con
                               const float* spheres, uint32_t n_spheres, uint8_t* out_rgba8);
 
 /* Host-side analysis the path tracer applies to a scene before choosing a kernel; touches no device, usable without a
- * GPU.  *out_class: bit 0 (MC_PT_SCENE_SLAB) — six axis-aligned planes in index order x,x,y,y,z,z plus three spheres
- * (the reference scene, pathtracerApp.h:14-39): the specialised slab kernels run; bit 1 (MC_PT_SCENE_LIGHTS_INSIDE) —
+ * GPU.  *out_class: bit 0 (MC_PT_SCENE_SLAB) — six axis-aligned planes in index order x,x,y,y,z,z plus one to eight spheres
+ * (the reference scene, pathtracerApp.h:14-39, has three): the specialised slab kernels run; bit 1 (MC_PT_SCENE_LIGHTS_INSIDE) —
  * additionally the planes close a box, the camera (pathTracer.comp:352) and every emissive sphere lie inside it with a
  * margin: shadow rays (pathTracer.comp:420) skip the plane tests.  Both specialisations are bit-exact;
- * every other scene takes the generic kernel.  Bit 2 (MC_PT_SCENE_SPHERES_DISJOINT) — slab scenes: the three spheres are pairwise
- * disjoint with a margin; only then does MC_PT_MATH_FAST take the sample-pool kernel, which orders the spheres a shadow ray meets by
- * the projections of their centres (strict math does not depend on it).  Bit 3 (MC_PT_SCENE_LIGHT_ENCLOSED) — any scene: an
+ * every other scene takes the generic kernel.  Bit 2 (MC_PT_SCENE_SPHERES_DISJOINT) — slab scenes: the spheres are pairwise
+ * disjoint with a margin; the fast sample-pool kernel then decides shadow rays without square roots, ordering the spheres a ray meets
+ * by the projections of their centres (overlapping spheres: its root form; strict math does not depend on it).  Bit 3 (MC_PT_SCENE_LIGHT_ENCLOSED) — any scene: an
  * emissive sphere intersects a non-emissive diffuse sphere (or comes within 1.5 of its own radii of it), or is all but enclosed by a
  * mirror sphere.  Next-event estimation at point-blank range through rays grazing the sphere they start on (pathTracer.comp:325-327,
  * 420) makes such an image a collection of near-ties, which fast math decides differently from the reference arithmetic far more
@@ -197,7 +197,7 @@ int mc_pathtrace_render_rgba8(mc_context* ctx, const mc_pathtrace_params* p, con
  * (bit-identical to the oracle), never silently outside the bound. */
 #define MC_PT_SCENE_SLAB 1u
 #define MC_PT_SCENE_LIGHTS_INSIDE 2u
-#define MC_PT_SCENE_SPHERES_DISJOINT 4u   /* slab scenes: the three spheres are pairwise disjoint (the fast sample-pool kernel's premise) */
+#define MC_PT_SCENE_SPHERES_DISJOINT 4u   /* slab scenes: the spheres are pairwise disjoint (the fast pool kernel then needs no square roots for shadow rays) */
 #define MC_PT_SCENE_LIGHT_ENCLOSED 8u     /* a light intersecting a diffuse sphere / all but enclosed by a mirror: fast math requests are rendered strict */
 int mc_pathtrace_scene_class(const float* planes, uint32_t n_planes, const float* spheres, uint32_t n_spheres,
                              uint32_t* out_class);

@@ -183,26 +183,31 @@ def _scene(O):
     return O.DEFAULT_PLANES.copy().reshape(6, 12), O.DEFAULT_SPHERES.copy().reshape(3, 12)
 
 
-def test_fast_pool_kernel_needs_disjoint_spheres(ctx, B, O):
-    """The fast pool kernel orders the spheres a shadow ray meets by the projections of their centres, which is the order of their
-    hits only for DISJOINT spheres (pathtrace_kernel.h, shadow_visible_disjoint): with two spheres pushed into each other the host
-    must take the round-synchronous closed-box kernel (same bits as MC_PT_NO_POOL_KERNEL), within the fast tolerance; the strict
-    pool kernel has no such premise and stays bit-identical."""
+def test_fast_pool_kernel_with_overlapping_spheres(ctx, B, O):
+    """The fast pool kernel decides shadow rays without square roots by ordering the spheres a ray meets by the projections of their
+    centres — the order of their hits only for DISJOINT spheres (pathtrace_kernel.h, shadow_visible_disjoint).  With two spheres pushed
+    into each other the host launches the pool kernel's other instantiation (round 4; before: the round-synchronous kernel), which
+    takes the roots (shadow_reaches_sphere): inside the fast tolerance of the oracle with libm, close to the round-synchronous
+    closed-box kernel (different instruction sequences, forked samples only); the strict pool kernel has no such premise."""
     planes, spheres = _scene(O)
     spheres[1, 0:3] = spheres[0, 0:3] + np.float32([0.9, 0.0, 0.3])   # the glass sphere cuts into the mirror sphere
-    W, H, spp = 96, 64, 64
-    fast = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST), planes=planes, spheres=spheres)
+    assert B.pathtrace_scene_class(planes, spheres) & B.PT_SCENE_SPHERES_DISJOINT == 0
+    W, H, spp = 96, 64, 256
+    q = B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST)
+    assert B.pathtrace_select_kernel(q, planes, spheres).kernel == B.PT_KERNEL_POOL
+    fast = ctx.pathtrace(q, planes=planes, spheres=spheres)
     rounds = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, flags=B.PT_NO_POOL_KERNEL), planes=planes, spheres=spheres)
-    assert np.array_equal(bits(fast), bits(rounds))
+    libm = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_LIBM)
+    for name, img in (("pool", fast), ("rounds", rounds)):
+        d = img[..., :3].astype(np.float64) - libm[..., :3].astype(np.float64)
+        rmse, p999 = float(np.sqrt((d ** 2).mean())), float(np.percentile(np.sqrt((d ** 2).sum(-1)), 99.9))
+        print(f"overlapping spheres, {name}: rmse {rmse:.4f}  p99.9 L2 {p999:.3f}  mean {d.mean():+.5f}")
+        assert np.isfinite(img).all() and rmse <= 0.4 and p999 <= 4.0 and abs(d.mean()) < 0.05, (name, rmse, p999)
     strict = ctx.pathtrace(B.pathtrace_params(W, H, spp), planes=planes, spheres=spheres)
     assert np.array_equal(bits(strict), bits(O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC)))
-    # and a hair's breadth apart they are disjoint for the host: the pool kernel runs (other bits than the round-synchronous kernel)
-    spheres[1, 0:3] = spheres[0, 0:3] + np.float32([1.7, 0.0, 0.0])
-    fast = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST), planes=planes, spheres=spheres)
-    rounds = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, flags=B.PT_NO_POOL_KERNEL), planes=planes, spheres=spheres)
-    assert not np.array_equal(bits(fast), bits(rounds))
-    d = fast[..., :3].astype(np.float64) - rounds[..., :3].astype(np.float64)
-    assert abs(d.mean()) < 0.05 and np.sqrt((d ** 2).mean()) < 1.0
+    # tiling invariance holds for this instantiation too
+    top = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, row_begin=0, row_end=32), planes=planes, spheres=spheres)
+    assert np.array_equal(bits(top), bits(fast[:32]))
 
 
 @pytest.mark.parametrize("case", ["light_is_sphere_0", "two_lights", "diffuse_sphere_and_mirror_wall"])

@@ -21,20 +21,21 @@ import __graft_entry__ as entry  # noqa: E402
 
 def scene(rng, O, enclose=False):
     planes = O.DEFAULT_PLANES.copy().reshape(6, 12)
-    spheres = O.DEFAULT_SPHERES.copy().reshape(3, 12)
+    ns = int(rng.choice([3, 3, 3, 1, 2, 4, 5, 6, 8]))          # 1 .. 8 spheres take the specialised kernels (round 4)
+    spheres = np.zeros((ns, 12), np.float32)
     planes[:, 3] *= rng.uniform(0.85, 1.25, 6).astype(np.float32)
     planes[:, 8:11] = rng.uniform(0.05, 0.999, (6, 3)).astype(np.float32)
     if rng.random() < 0.4:
         planes[rng.integers(6), 11] = 2.0                       # a mirror wall (a wall of glass leaves the closed-box class)
     lo = np.array([-planes[0, 3], -planes[3, 3], -planes[4, 3]]) + 0.3
     hi = np.array([planes[1, 3], planes[2, 3], min(planes[5, 3], 3.0)]) - 0.3
-    for i in range(3):
+    for i in range(ns):
         spheres[i, 3] = np.float32(rng.choice([rng.uniform(0.05, 0.3), rng.uniform(0.3, 1.0), rng.uniform(1.0, 1.6)], p=[0.3, 0.6, 0.1]))
         spheres[i, 0:3] = rng.uniform(lo, hi).astype(np.float32)
         spheres[i, 8:11] = rng.uniform(0.0, 0.999, 3).astype(np.float32)
         spheres[i, 11] = float(rng.choice([1, 2, 3]))
         spheres[i, 4:7] = 0
-    for i in rng.choice(3, int(rng.integers(1, 3)), replace=False):   # one or two lights, small, well inside the room
+    for i in rng.choice(ns, int(rng.integers(1, min(ns, 2) + 1)), replace=False):   # one or two lights, small, well inside the room
         spheres[i, 4:7] = rng.uniform(5, 120, 3).astype(np.float32)
         spheres[i, 8:11] = 0
         spheres[i, 11] = 1.0
@@ -45,8 +46,8 @@ def scene(rng, O, enclose=False):
     # them with the strict kernels — main() expects the oracle's bits there.  `enclose` aims a share of the scenes AT that boundary:
     # a light placed so that it pokes out of an opaque sphere by -0.5 ... 5 of its own radii.
     if enclose and rng.random() < 0.35:
-        lights = [i for i in range(3) if spheres[i, 4:7].any()]
-        darks = [j for j in range(3) if not spheres[j, 4:7].any()]
+        lights = [i for i in range(ns) if spheres[i, 4:7].any()]
+        darks = [j for j in range(ns) if not spheres[j, 4:7].any()]
         if lights and darks:
             i, j = int(rng.choice(lights)), int(rng.choice(darks))
             spheres[j, 3] = np.float32(rng.uniform(0.5, 1.1))

@@ -61,7 +61,8 @@ def fuzz_mandel_ds(rng, ctx, B, O):
 
 def fuzz_pathtrace(rng, ctx, B, O):
     planes = O.DEFAULT_PLANES.copy().reshape(6, 12)
-    spheres = O.DEFAULT_SPHERES.copy().reshape(3, 12)
+    ns = int(rng.choice([3, 3, 3, 1, 2, 4, 5, 6, 7, 8]))       # 1 .. 8 spheres take the specialised kernels (round 4)
+    spheres = np.zeros((ns, 12), np.float32)
     # walls: jitter offsets and colours, sometimes make one specular
     planes[:, 3] *= rng.uniform(0.8, 1.3, 6).astype(np.float32)
     planes[:, 8:11] = rng.uniform(0.1, 0.999, (6, 3)).astype(np.float32)
@@ -70,13 +71,13 @@ def fuzz_pathtrace(rng, ctx, B, O):
     # spheres: positions anywhere in / around the room, any material, one or more lights
     lo = np.array([-planes[0, 3], -planes[3, 3], -planes[4, 3]]) - 0.5
     hi = np.array([planes[1, 3], planes[2, 3], min(planes[5, 3], 3.0)]) + 0.5
-    for i in range(3):
+    for i in range(ns):
         spheres[i, 0:3] = rng.uniform(lo, hi).astype(np.float32)
         spheres[i, 3] = np.float32(rng.uniform(0.05, 1.0))
         spheres[i, 8:11] = rng.uniform(0.0, 0.999, 3).astype(np.float32)
         spheres[i, 11] = float(rng.choice([1, 1, 2, 3]))
         spheres[i, 4:7] = 0
-    for i in rng.choice(3, int(rng.integers(1, 3)), replace=False):
+    for i in rng.choice(ns, int(rng.integers(1, min(ns, 3) + 1)), replace=False):
         spheres[i, 4:7] = rng.uniform(5, 120, 3).astype(np.float32)
         spheres[i, 8:11] = 0
         spheres[i, 11] = 1.0
@@ -88,9 +89,9 @@ def fuzz_pathtrace(rng, ctx, B, O):
         if rng.random() < 0.5:
             planes[rng.integers(6), 11] = code
         else:
-            spheres[rng.integers(3), 11] = code
+            spheres[rng.integers(ns), 11] = code
     if rng.random() < 0.05:   # extreme radii: roots far outside / tiny discriminants
-        spheres[rng.integers(3), 3] = np.float32(rng.choice([1e-3, 1e-2, 5.0, 30.0]))
+        spheres[rng.integers(ns), 3] = np.float32(rng.choice([1e-3, 1e-2, 5.0, 30.0]))
     W, H, spp = int(rng.integers(1, 40)), int(rng.integers(1, 28)), int(rng.integers(1, 20))
     if rng.random() < 0.25:   # sample counts beyond the pool kernel's batch (16) and result-ring (64) sizes, on a small image
         W, H, spp = int(rng.integers(1, 12)), int(rng.integers(1, 10)), int(rng.integers(20, 200))
@@ -99,10 +100,20 @@ def fuzz_pathtrace(rng, ctx, B, O):
     flags = int(rng.choice([0, 0, 0, B.pt_force_s(1), B.pt_force_s(4), B.pt_force_s(16), B.PT_GENERIC_KERNEL, B.PT_NO_POOL_KERNEL,
                             B.PT_GENERIC_KERNEL | B.PT_SCENE_IN_MEMORY]))   # (the last: the generic kernel reading the scene from memory)
     cls = B.pathtrace_scene_class(planes, spheres)
-    out = ctx.pathtrace(B.pathtrace_params(W, H, spp, max_depth=depth, flags=flags), planes=planes, spheres=spheres)
+    # a third of the cases as a progressive render in two sample ranges and / or as two row tiles (any alignment)
+    cut = int(rng.integers(1, spp)) if spp > 1 and rng.random() < 0.3 else 0
+    rcut = int(rng.integers(1, H)) if H > 1 and rng.random() < 0.3 else 0
+    tiles = []
+    for r0, r1 in ([(0, rcut), (rcut, H)] if rcut else [(0, H)]):
+        acc = None
+        for s0, s1 in ([(0, cut), (cut, spp)] if cut else [(0, spp)]):
+            acc = ctx.pathtrace(B.pathtrace_params(W, H, spp, max_depth=depth, flags=flags, sample_begin=s0, sample_end=s1,
+                                                   row_begin=r0, row_end=r1), planes=planes, spheres=spheres, acc=acc)
+        tiles.append(acc)
+    out = np.concatenate(tiles)
     ref = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC, max_depth=depth)
     ok = np.array_equal(bits(out), bits(ref))
-    return ok, (f"pt class={cls} W={W} H={H} spp={spp} depth={depth} flags={flags}\nplanes={planes.tolist()}\n"
+    return ok, (f"pt class={cls} W={W} H={H} spp={spp} depth={depth} flags={flags} sample cut {cut} row cut {rcut}\nplanes={planes.tolist()}\n"
                 f"spheres={spheres.tolist()}"), cls
 
 
@@ -116,7 +127,7 @@ def main():
     ctx = B.Context(0)
     rng = np.random.default_rng(args.seed)
     counts = {"f32": 0, "ds": 0, "pt": 0}
-    classes = {0: 0, 1: 0, 3: 0}
+    classes = {}
     bad = {}
     t0 = last = time.time()
     while time.time() - t0 < args.seconds:
@@ -131,7 +142,7 @@ def main():
         if time.time() - last > 30:
             last = time.time()
             print(f"[{last - t0:5.0f} s] cases {counts} pt scene classes {classes} mismatching families {list(bad)}", flush=True)
-    print(f"done: cases {counts}, pt scene classes (0 generic, 1 slab, 3 slab + shadow shortcut) {classes}, "
+    print(f"done: cases {counts}, pt scene classes (bit 0 slab, 1 lights inside, 2 disjoint, 3 light intersects a diffuse sphere) {classes}, "
           f"mismatching families {list(bad)}")
     ctx.close()
     return 1 if bad else 0

@@ -298,9 +298,8 @@ int pathtrace_plan(const mc_pathtrace_params* p, const float* planes, uint32_t n
         const bool aligned = p->row_begin % th == 0u && (a.row_block == 0u || (a.row_block % th == 0u && a.row_stride % th == 0u)) &&
                              (p->row_end % th == 0u || p->row_end == p->height);
         const bool fits = p->max_depth >= 1u && (uint64_t)p->spp * p->max_depth < (1ull << 32) && p->width < (1u << 24);
-        // (the fast pool kernel orders a shadow ray's spheres by their centres' projections: disjoint spheres only)
-        if (auto_width && !(p->flags & MC_PT_NO_POOL_KERNEL) && (aligned || !fast) && fits &&
-            (!fast || a.scene.spheres_disjoint))
+        // (fast, pairwise disjoint spheres: shadow rays decided without square roots; overlapping spheres: the pool kernel's root form)
+        if (auto_width && !(p->flags & MC_PT_NO_POOL_KERNEL) && (aligned || !fast) && fits)
             variant = 4;
     }
     plan.variant = variant;

@@ -478,7 +478,7 @@ __device__ __forceinline__ int intersect_slab(const HotSlabN<NS>& h, v3 o, v3 d,
 // The reference keeps a later candidate only if it is STRICTLY nearer, so sphere li wins iff its root dd_li is finite,
 // strictly below every root of the spheres before it and not above any root of the spheres after it.  dd_k is the value the
 // loop assigns for sphere k (:319-327), 1e20 when there is none.  Same comparisons on the same values: exact.
-template <bool Fast, int NS>
+template <bool Fast, bool OccR2 = false, int NS = 3>   // OccR2: occ[i] holds |c_i - o|^2 - r_i^2 (the fast pool kernel's form)
 __device__ __forceinline__ bool shadow_reaches_sphere(const HotSlabN<NS>& h, v3 o, v3 d, int li, v3 oc_li, const float* occ) {
     MC_PT_DECISION_FP
     float dd[NS];
@@ -487,7 +487,7 @@ __device__ __forceinline__ bool shadow_reaches_sphere(const HotSlabN<NS>& h, v3 
         // centre - o of the light (:408) and all three squared lengths were formed by the caller: the same operations
         const v3 oc = i == li ? oc_li : v3{h.c[i][0], h.c[i][1], h.c[i][2]} - o;   // :317
         float b = dot(oc, d);                                                // :318
-        float det = (b * b - occ[i]) + h.r2[i];
+        float det = OccR2 ? b * b - occ[i] : (b * b - occ[i]) + h.r2[i];
         float r = h.inf;
         if (!(det < 0.0f)) {                                                 // :319
             float sq = dm::fsqrt<Fast>(det);

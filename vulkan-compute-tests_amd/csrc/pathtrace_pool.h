@@ -71,7 +71,9 @@ template <bool Fast, int NS> constexpr int pool_waves() {
     return Fast ? (NS <= 3 ? MC_PT_POOL_WAVES : NS <= 5 ? 6 : NS <= 6 ? 5 : 4) : (NS <= 3 ? MC_PT_POOL_STRICT_WAVES : NS <= 6 ? 4 : 3);
 }
 
-template <bool Fast, int S, int NS>
+// Disjoint (fast math): the host proved the spheres pairwise disjoint — shadow rays are decided without square roots
+// (shadow_visible_disjoint); false: overlapping spheres, the root form (shadow_reaches_sphere).  The strict kernel has one form.
+template <bool Fast, int S, int NS, bool Disjoint = true>
 __global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_kernel(PTArgs a) {
     constexpr uint32_t kPoolRecordFloats = pool_record_floats<NS>();
     extern __shared__ float lds_dyn[];
@@ -304,8 +306,8 @@ __global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_
                         float cos_a_max;
                         v3 l = light_sample_direction<Fast>(xoc[i], xcc[i], hot.r2[i], rnd, cos_a_max);   // :408-:413
                         bool lit;                                                                          // :420
-                        if constexpr (Fast) lit = shadow_visible_disjoint<kOccR2>(hot, l, i, xoc, occ);            // (the host selects this kernel for disjoint spheres)
-                        else lit = shadow_reaches_sphere<Fast>(hot, x, l, i, xoc[i], occ);
+                        if constexpr (Fast && Disjoint) lit = shadow_visible_disjoint<kOccR2>(hot, l, i, xoc, occ);
+                        else lit = shadow_reaches_sphere<Fast, kOccR2>(hot, x, l, i, xoc[i], occ);
                         if (lit) {
                             MC_REGION(8);    // light contribution
                             if constexpr (Fast) {
@@ -403,7 +405,8 @@ __global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_
 template <bool Fast, int S, int NS> inline int launch_pool_one(const PTArgs& a, uint32_t tile_rows, hipStream_t s) {
     dim3 grid((a.W + block_w<S>() - 1u) / block_w<S>(), (tile_rows + block_h<S>() - 1u) / block_h<S>());
     constexpr size_t lds = pool_block_lds_bytes<Fast, NS>();
-    hipLaunchKernelGGL((pathtrace_pool_kernel<Fast, S, NS>), grid, dim3(256), lds, s, a);
+    if (Fast && !a.scene.spheres_disjoint) hipLaunchKernelGGL((pathtrace_pool_kernel<Fast, S, NS, false>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((pathtrace_pool_kernel<Fast, S, NS, true>), grid, dim3(256), lds, s, a);
     return MC_OK;
 }
 // variant 4 of launch_fast / launch_strict: 16 lanes per pixel and batch (the host never passes anything else); one instantiation
