@@ -20,7 +20,7 @@
 //
 // STRICT variant (Fast = false; bit-identical to the oracle like every strict kernel): the per-pixel sum must be the reference's —
 // samples added in sample order (:451-:452).  A lane therefore keeps a per-PATH accrad, writes accrad / spp into its sample's slot
-// of a result ring in LDS (four batches per pixel) when the path ends, and the pixel's 16 lanes add a batch's 16 results in sample
+// of a result ring in LDS (three batches per pixel for the reference scene, four beyond three spheres) when the path ends, and the pixel's 16 lanes add a batch's 16 results in sample
 // order — the fold of the round-synchronous kernels, fed from LDS — once every sample of the batch has ended (oldest live sample
 // of the pixel by a 4-step butterfly, only when a new batch is wanted).  Same decisions, same operations, same order: exact.
 //
@@ -39,7 +39,7 @@
 #define MC_PT_POOL_WAVES 7   // waves per SIMD the register budget is set for (72 VGPRs; 6: 18.29 ms, 7: 18.11, 8: 18.68 at K2)
 #endif
 #ifndef MC_PT_POOL_STRICT_WAVES
-#define MC_PT_POOL_STRICT_WAVES 5   // strict kernel: 95 VGPRs
+#define MC_PT_POOL_STRICT_WAVES 6   // strict kernel: 80 VGPRs (8 values spilled outside the bounce loop), 6 blocks of 26 KB per CU
 #endif
 #ifndef MC_PT_POOL_KEEP_VALID   // the pixel's validity kept across the loop (a lane mask) instead of re-derived per batch
 #define MC_PT_POOL_KEEP_VALID 1
@@ -61,11 +61,17 @@ constexpr uint32_t kPoolEntryFloats = 8;     // {rd.x, rd.y, rd.z, t | id (-1: n
 constexpr uint32_t kPoolRecordStride = 16;   // floats per staged record: {geo.xyz, p (fast: 1 / p) | colour.rgb, material + 256 * emits | emission.xyz, RN(1 / p) (fast: p) | fast: colour.rgb / p, the same integer bits}
 template <int NS> constexpr uint32_t pool_record_floats() { return (6u + (uint32_t)NS) * kPoolRecordStride; }   // 6 planes + NS spheres
 constexpr uint32_t kPoolStashFloats = 128u * kPoolEntryFloats;     // per wave: 64/S pixels x 2 batches x S entries
-constexpr uint32_t kPoolResultBatches = 4;                         // strict: result ring of 4 batches per pixel, 3 planes (x, y, z)
-constexpr uint32_t kPoolResultFloats = 64u * kPoolResultBatches * 3u;   // per wave: 64/S pixels x 4 batches x S samples x 3
-template <bool Fast> constexpr uint32_t pool_wave_lds_floats() { return kPoolStashFloats + (Fast ? 0u : kPoolResultFloats); }
-template <bool Fast, int NS> constexpr size_t pool_block_lds_bytes() { return (pool_record_floats<NS>() + 4u * pool_wave_lds_floats<Fast>()) * sizeof(float); }
-// Waves per SIMD the register budget is set for: 7 / 5 for the reference's three spheres (72 / 95 VGPRs); every further sphere
+// Strict: the result ring holds this many batches per pixel (3 planes x, y, z).  Three for the reference's scene: with the 23 + 3 KB of a
+// block six blocks fit a CU's 160 KB, and 6 waves per SIMD with a 3-batch ring beat 5 waves with a 4-batch ring (32.7 against 33.1 ms at K2;
+// 2 batches stall the production: 34.3; profiles/r04_strict_occupancy.txt).  Scenes with more spheres run at 4 waves per SIMD: 4 batches.
+#ifndef MC_PT_POOL_RESULT_BATCHES
+#define MC_PT_POOL_RESULT_BATCHES 0   // 0: automatic (by sphere count)
+#endif
+template <int NS> constexpr uint32_t pool_result_batches() { return MC_PT_POOL_RESULT_BATCHES ? MC_PT_POOL_RESULT_BATCHES : (NS <= 3 ? 3u : 4u); }
+template <int NS> constexpr uint32_t pool_result_floats() { return 64u * pool_result_batches<NS>() * 3u; }   // per wave: 64/S pixels x batches x S samples x 3
+template <bool Fast, int NS> constexpr uint32_t pool_wave_lds_floats() { return kPoolStashFloats + (Fast ? 0u : pool_result_floats<NS>()); }
+template <bool Fast, int NS> constexpr size_t pool_block_lds_bytes() { return (pool_record_floats<NS>() + 4u * pool_wave_lds_floats<Fast, NS>()) * sizeof(float); }
+// Waves per SIMD the register budget is set for: 7 / 6 for the reference's three spheres (72 / 80 VGPRs); every further sphere
 // keeps five more values live across a bounce (c_i - x, |c_i - x|^2 and its r^2-reduced form), so the budget widens with the count.
 template <bool Fast, int NS> constexpr int pool_waves() {
     return Fast ? (NS <= 3 ? MC_PT_POOL_WAVES : NS <= 5 ? 6 : NS <= 6 ? 5 : 4) : (NS <= 3 ? MC_PT_POOL_STRICT_WAVES : NS <= 6 ? 4 : 3);
@@ -100,7 +106,7 @@ __global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_
     // fast math: the sphere tests of a bounce (three of the shadow ray, three of the next ray, all from the hit point x) read
     // |c_i - x|^2 - r_i^2, formed once, instead of each adding r_i^2 to its b^2 - |c_i - x|^2
     constexpr bool kOccR2 = Fast && MC_PT_FAST_OCC_MINUS_R2;
-    constexpr uint32_t TW = WaveTile<S>::w, TH = WaveTile<S>::h, Ring = 2u * (uint32_t)S, RRing = kPoolResultBatches * (uint32_t)S;
+    constexpr uint32_t TW = WaveTile<S>::w, TH = WaveTile<S>::h, Ring = 2u * (uint32_t)S, RRing = pool_result_batches<NS>() * (uint32_t)S;
     HotSlabN<NS> hot;
     hot.template load<MC_PT_POOL_HOT_VGPR, MC_PT_POOL_HOT_W>(a.scene);   // (uniform operands: this kernel has no vector registers to spare for copies)
     // A lane's pixel (pix = lane / S of the wave tile) and slot of a batch (sub = lane % S) never change.  What derives from them
@@ -124,10 +130,10 @@ __global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_
     // my pixel's coordinates (:349) stay: the RNG key of every bounce needs them; so does the base of its stash
     uint32_t gx, gy;
     bool pixel_valid;         // my pixel lies in the image and in the tile (:348)
-    float* const gstash = lds_dyn + kPoolRecordFloats + (threadIdx.x >> 6) * pool_wave_lds_floats<Fast>() +
+    float* const gstash = lds_dyn + kPoolRecordFloats + (threadIdx.x >> 6) * pool_wave_lds_floats<Fast, NS>() +
                           ((threadIdx.x & 63u) / (uint32_t)S) * (Ring * kPoolEntryFloats);
     // strict: my pixel's result ring [3][RRing] (x, y, z planes) behind the wave's stash
-    float* const gres = lds_dyn + kPoolRecordFloats + (threadIdx.x >> 6) * pool_wave_lds_floats<Fast>() + kPoolStashFloats +
+    float* const gres = lds_dyn + kPoolRecordFloats + (threadIdx.x >> 6) * pool_wave_lds_floats<Fast, NS>() + kPoolStashFloats +
                         ((threadIdx.x & 63u) / (uint32_t)S) * (3u * RRing);
     {
         const uint32_t tid = threadIdx.x, wave = tid >> 6, pix = (tid & 63u) / (uint32_t)S;
@@ -194,7 +200,7 @@ __global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_
                     const uint32_t fin = oldest < ghead ? oldest : ghead;             // samples [0, fin) are taken and ended
                     while (committed + (uint32_t)S <= fin) {
                         for (uint32_t k = 0; k < (uint32_t)S; k++) {                  // :452 acc += accrad / spp, in sample order
-                            const uint32_t slot = (committed + k) & (RRing - 1u);
+                            const uint32_t slot = (committed + k) % RRing;
                             acc.x += gres[slot]; acc.y += gres[RRing + slot]; acc.z += gres[2u * RRing + slot];
                         }
                         committed += (uint32_t)S;
@@ -220,7 +226,7 @@ __global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_
                 // gathers nothing either
                 if (!((MC_PT_POOL_KEEP_VALID ? pixel_valid : g.valid) && samp < a.sample_end)) cid = -1;
                 if constexpr (!Fast) {   // such a sample's result is a zero (adding +0 changes no bit of the sum)
-                    const uint32_t slot = (batch * (uint32_t)S + g.sub) & (RRing - 1u);
+                    const uint32_t slot = (batch * (uint32_t)S + g.sub) % RRing;
                     if (cid < 0) { gres[slot] = 0.0f; gres[RRing + slot] = 0.0f; gres[2u * RRing + slot] = 0.0f; }
                 }
                 float4* e = reinterpret_cast<float4*>(gstash + ((batch * (uint32_t)S + g.sub) & (Ring - 1u)) * kPoolEntryFloats);
@@ -354,7 +360,7 @@ __global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_
                 if constexpr (!Fast) {
                     if (!go) {   // the path has ended: :452's accrad / samps.y into the sample's slot of the result ring
                         const v3 q = divs_recip<Fast>(accrad, fspp, a.inv_spp);
-                        const uint32_t slot = cur & (RRing - 1u);
+                        const uint32_t slot = cur % RRing;
                         gres[slot] = q.x; gres[RRing + slot] = q.y; gres[2u * RRing + slot] = q.z;
                     }
                 }
@@ -387,7 +393,7 @@ __global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_
         // ---- every sample of the pool has ended: the batches not yet added, in sample order (entries beyond the sample range hold zeros)
         while (committed < n_batches * (uint32_t)S) {
             for (uint32_t k = 0; k < (uint32_t)S; k++) {
-                const uint32_t slot = (committed + k) & (RRing - 1u);
+                const uint32_t slot = (committed + k) % RRing;
                 acc.x += gres[slot]; acc.y += gres[RRing + slot]; acc.z += gres[2u * RRing + slot];
             }
             committed += (uint32_t)S;
