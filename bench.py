@@ -365,7 +365,10 @@ def main():
         if is_pt:   # the kernel the host selected for this request (mc_pathtrace_select_kernel: the same decision the launch made)
             ki = B.pathtrace_select_kernel(p)
             fast_ran = ki.math_mode == B.PT_MATH_FAST
-            kern = (f"pathtrace_pool_kernel<{'true' if fast_ran else 'false'}, {ki.lanes_per_pixel}, 3>" if ki.kernel == B.PT_KERNEL_POOL
+            pl, sp = B.default_scene()
+            disjoint = (not fast_ran) or bool(B.pathtrace_scene_class(pl, sp) & B.PT_SCENE_SPHERES_DISJOINT)   # (template default: true)
+            kern = (f"pathtrace_pool_kernel<{'true' if fast_ran else 'false'}, {ki.lanes_per_pixel}, 3, {'true' if disjoint else 'false'}>"
+                    if ki.kernel == B.PT_KERNEL_POOL
                     else f"pathtrace_kernel<{B.PT_KERNEL_NAMES[ki.kernel]}, fast={str(fast_ran).lower()}, S={ki.lanes_per_pixel}>")
         else:
             kern = "mandelbrot_kernel<StateDS>" if cfg["ds"] else "mandelbrot_kernel<StateF32>"
