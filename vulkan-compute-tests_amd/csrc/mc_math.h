@@ -136,6 +136,9 @@ template <bool Fast> __device__ __forceinline__ float fsqrt(float a) {
     if (Fast) return a * nt_rsq(a);
 #endif
     if (Fast) return __builtin_amdgcn_sqrtf(a);
+#ifdef MC_EXPERIMENT_NO_WINDOW_GUARD   // measurement only: what the per-call window tests cost (NOT exact outside the window)
+    return sqrt_short(a);
+#endif
     if (__builtin_expect(wave_all(in_short_window(a)), 1)) return sqrt_short(a);
     return ieee_sqrt(a);
 }
@@ -144,6 +147,9 @@ template <bool Fast> __device__ __forceinline__ float inversesqrt(float a) {
     if (Fast) return nt_rsq(a);
 #endif
     if (Fast) return __builtin_amdgcn_rsqf(a);
+#ifdef MC_EXPERIMENT_NO_WINDOW_GUARD
+    return rsqrt_short(a);
+#endif
     if (__builtin_expect(wave_all(in_short_window(a)), 1))
         return MC_MATH_RSQRT_ONE_TRANS ? rsqrt_short(a) : rcp_short(sqrt_short(a));   // (sqrt in [2^-50, 2^50): inside rcp_short's window)
     return ieee_div(1.0f, ieee_sqrt(a));
