@@ -46,14 +46,3 @@ extern "C" int mc_debug_pt_region_stats(unsigned long long* exec16, unsigned lon
 }
 #endif
 
-#ifdef MC_PT_WAVE_TIME
-// Diagnostic build (make wavetime): read and reset the per-region wave-cycle sums and mark counts of the fast kernels.
-extern "C" int mc_debug_pt_wave_time(unsigned long long* cycles32, unsigned long long* marks32) {
-    unsigned long long zero[32] = {0};
-    if (hipMemcpyFromSymbol(cycles32, HIP_SYMBOL(mc::pt::g_wave_time), sizeof(zero)) != hipSuccess) return 3;
-    if (hipMemcpyFromSymbol(marks32, HIP_SYMBOL(mc::pt::g_wave_marks), sizeof(zero)) != hipSuccess) return 3;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(mc::pt::g_wave_time), zero, sizeof(zero)) != hipSuccess) return 3;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(mc::pt::g_wave_marks), zero, sizeof(zero)) != hipSuccess) return 3;
-    return 0;
-}
-#endif

@@ -162,15 +162,11 @@ __device__ __forceinline__ v3 rand01(uint32_t x, uint32_t y, uint32_t z) {
     return v3{(float)x * s, (float)y * s, (float)z * s};
 }
 
-// Diagnostic build only (make stats -> lib/libmc_compute_stats.so, tools/pt_region_stats.py): how often each code
+// Diagnostic build only (make stats -> lib/libmc_compute_stats.so, tools/pool_region_stats.py): how often each code
 // region is executed by a wave and with how many active lanes — the divergence picture behind DESIGN.md §3.3.
 #ifdef MC_PT_REGION_STATS
 static __device__ unsigned long long g_region_exec[32];
 static __device__ unsigned long long g_region_lanes[32];
-#ifdef MC_PT_REGION_TIME
-#define MC_REGION(r) do { } while (0)
-#define MC_ACCUM(r, value) do { } while (0)
-#else
 #define MC_REGION(r)                                                                            \
     do {                                                                                        \
         unsigned long long m_ = __ballot(1);                                                    \
@@ -179,75 +175,8 @@ static __device__ unsigned long long g_region_lanes[32];
             atomicAdd(&g_region_lanes[r], (unsigned long long)__popcll(m_));                    \
         }                                                                                       \
     } while (0)
-// accumulates a wave-uniform value (the "lanes" column then holds its sum, "exec" the number of observations)
-#define MC_ACCUM(r, value)                                                                      \
-    do {                                                                                        \
-        unsigned long long m_ = __ballot(1);                                                    \
-        if ((int)__lane_id() == __ffsll((long long)m_) - 1) {                                   \
-            atomicAdd(&g_region_exec[r], 1ull);                                                 \
-            atomicAdd(&g_region_lanes[r], (unsigned long long)(value));                         \
-        }                                                                                       \
-    } while (0)
-#endif
-// MC_PT_REGION_TIME (with MC_PT_REGION_STATS): wall cycles of a wave between two marks, summed per region
-// Accumulated in (scalar) registers and flushed once per wave (MC_TIME_FLUSH), so the marks do not stretch the code
-// between them with global atomics.
-#ifdef MC_PT_REGION_TIME
-#define MC_TIME_INIT unsigned long long mc_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned int mc_cnt_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long mc_t_ = 0
-#define MC_TIME_DECL mc_t_ = __builtin_amdgcn_s_memtime()
-#define MC_TIME_MARK(r)                                                                         \
-    do {                                                                                        \
-        const unsigned long long n_ = __builtin_amdgcn_s_memtime();                             \
-        mc_acc_[r] += n_ - mc_t_; mc_cnt_[r]++;                                                 \
-        mc_t_ = n_;                                                                             \
-    } while (0)
-#define MC_TIME_COUNT(r, v) do { mc_acc_[r] += (unsigned long long)(v); mc_cnt_[r]++; } while (0)   /* register-held counter */
-#define MC_TIME_FLUSH                                                                           \
-    do {                                                                                        \
-        if (__lane_id() == 0u)                                                                  \
-            for (int r_ = 0; r_ < 12; r_++) { atomicAdd(&g_region_exec[r_], (unsigned long long)mc_cnt_[r_]); atomicAdd(&g_region_lanes[r_], mc_acc_[r_]); } \
-    } while (0)
-#else
-#define MC_TIME_INIT do { } while (0)
-#define MC_TIME_DECL do { } while (0)
-#define MC_TIME_MARK(r) do { } while (0)
-#define MC_TIME_COUNT(r, v) do { } while (0)
-#define MC_TIME_FLUSH do { } while (0)
-#endif
 #else
 #define MC_REGION(r) do { } while (0)
-#define MC_ACCUM(r, value) do { } while (0)
-#define MC_TIME_INIT do { } while (0)
-#define MC_TIME_DECL do { } while (0)
-#define MC_TIME_MARK(r) do { } while (0)
-#define MC_TIME_COUNT(r, v) do { } while (0)
-#define MC_TIME_FLUSH do { } while (0)
-#endif
-
-// Diagnostic build only (make wavetime -> lib/libmc_compute_wavetime.so, tools/pt_wave_time.py): shader cycles a wave spends between
-// consecutive marks of the bounce loop, summed per region in LDS and flushed once per block — where the TIME of an iteration
-// goes, as opposed to where its instructions are (the two differ: issue classes, EXEC-empty instructions, dependency stalls).
-// A mark attributes the cycles since the previous mark (of any region) to its region; the first active lane books them.
-#ifdef MC_PT_WAVE_TIME
-static __device__ unsigned long long g_wave_time[32];
-static __device__ unsigned long long g_wave_marks[32];
-// (the time of the wave's previous mark lives in LDS, one word per wave: a C variable assigned inside divergent control flow
-// would become a per-lane value, and a lane that left the loop early would book the iterations it sat out)
-struct WaveTime { unsigned int* lds; unsigned int slot; };
-#define MC_WT(r)                                                                                \
-    do {                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-        const unsigned int n_ = (unsigned int)__builtin_amdgcn_s_memtime();                     \
-        const unsigned long long m_ = __ballot(1);                                              \
-        if ((int)__lane_id() == __ffsll((long long)m_) - 1) {                                   \
-            atomicAdd(&wt.lds[r], n_ - wt.lds[wt.slot]); atomicAdd(&wt.lds[32 + (r)], 1u);      \
-            wt.lds[wt.slot] = (unsigned int)__builtin_amdgcn_s_memtime();                       \
-        }                                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-    } while (0)
-#else
-struct WaveTime {};
-#define MC_WT(r) do { } while (0)
 #endif
 
 // Fast mode only: MC_PT_FAST_CONTRACT selects where the compiler may contract a*b+c (pathtrace_fast.hip):
@@ -843,7 +772,7 @@ template <bool Slab, int NS> constexpr int slab_spheres() { return Slab && NS > 
 template <bool Fast, int NP, int NS, bool Slab, int Prec, bool Box = false>
 __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restrict__ lds_obj,
                                            const uint32_t* __restrict__ lds_emissive, const HotSlabN<slab_spheres<Slab, NS>()>& hot,
-                                           uint32_t gx, uint32_t gy, uint32_t samp, WaveTime& wt) {
+                                           uint32_t gx, uint32_t gy, uint32_t samp) {
     constexpr int HS = slab_spheres<Slab, NS>();
     const SceneArgs& sc = a.scene;
     constexpr bool LdsScene = NP < 0;
@@ -873,7 +802,6 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
         for (int i = 0; i < HS; i++) { oc0[i] = v3{a.cam_oc[i][0], a.cam_oc[i][1], a.cam_oc[i][2]}; occ[i] = a.cam_occ[i]; }
         if (a.max_depth != 0u) id = intersect_slab<Fast, Box>(hot, ro, rd, t, false, occ, oc0);   // (Box: closed-box form, see intersect_slab)
     }
-    MC_WT(7);   // ray generation + the camera ray's intersection
     for (uint32_t depth = 0; depth < a.max_depth; depth++) {              // :367
         if constexpr (!Slab) {
             MC_REGION(1);   // primary intersect
@@ -925,7 +853,6 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
         // every material 1..3 continues from x (:429,:434,:447): with all materials known (uniform) the assignment is made once,
         // ahead of the dispatch, so that no branch has to copy it at the merge
         if constexpr (Slab) { if (Box || sc.materials_known) ro = x; }
-        MC_WT(0);   // prologue: hit point, c - x, record fetch, normal, emission, rand01, Russian roulette
         if (mat == 1) {                                                   // :400 diffuse
             MC_REGION(3);   // diffuse: NEE set-up + shadow ray
             const int n_lights = LdsScene ? (int)sc.n_emissive : ns;
@@ -950,7 +877,6 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 float cos_a_max;
                 v3 l = light_sample_direction<Fast>(xc, xcc, lr2, rnd, cos_a_max);   // :409-:413
                 float tne;
-                MC_WT(1);   // light sample: cone, basis, direction
                 bool reached;                                             // :420 shadow ray: is the nearest hit sphere i?
                 if constexpr (Slab) {
                     // (closed-box kernel, disjoint spheres — a uniform scene fact: the root-free test of the sample-pool kernel)
@@ -960,7 +886,6 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 } else {
                     reached = intersect<Fast, NP, NS, Slab, Prec>(sc, uobj, x, l, tne, false) == np + i;
                 }
-                MC_WT(2);   // shadow ray
                 if (reached) {
                     MC_REGION(4);   // shadow ray reached the light
                     float omega = (2.0f * kPi) * (1.0f - cos_a_max);      // :421
@@ -972,7 +897,6 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                     }
                 }
             }
-            MC_WT(3);   // light contribution
             MC_REGION(8);   // diffuse bounce direction
             // :426-:428.  Slab kernels: a bounce off a wall (axis-aligned, facing the ray: nl = -n) needs no tangent basis — the
             // same values, see cosine_bounce_wall; the general form only when some lane of the wave bounces off a diffuse sphere.
@@ -980,7 +904,6 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             else rd = cosine_bounce<Fast, Slab>(nl, rnd);
             if (!Slab || (!Box && !sc.materials_known)) ro = x;   // (slab scenes of known materials: moved ahead of the dispatch)
             emissive = 0.0f;                                              // :429
-            MC_WT(4);   // diffuse bounce direction
         } else if (mat == 2 || mat == 3) {                                // :432 mirror, :437 glass
             // one block for both specular materials: the glass branch needs reflect(rd, n) (:444, :446) — the mirror's whole
             // bounce (:433) — so a wave that holds lanes of both kinds evaluates it once
@@ -993,7 +916,6 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             }   // (general form)
             if (!Slab || (!Box && !sc.materials_known)) ro = x;   // (slab scenes of known materials: moved ahead of the dispatch)
             emissive = 1.0f;                                              // :447
-            MC_WT(5);   // mirror / glass
         }
         if constexpr (Slab) {
             if (depth + 1u < a.max_depth) {                               // (uniform) the intersection of the next depth
@@ -1004,7 +926,6 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 }
                 id = intersect_slab<Fast, Box>(hot, ro, rd, t, false, occ, xoc);
             }
-            MC_WT(6);   // intersection of the next depth
         }
     }
     return accrad;
@@ -1068,15 +989,6 @@ __global__ void __launch_bounds__(256, (rounds_waves<Fast, Slab, NS>())) pathtra
         c.idx = c.valid ? (size_t)ty * a.W + c.gx : 0;
         return c;
     };
-    WaveTime wt;
-#ifdef MC_PT_WAVE_TIME
-    __shared__ unsigned int lds_wave_time[72];
-    if (threadIdx.x < 64u) lds_wave_time[threadIdx.x] = 0u;
-    __syncthreads();
-    wt.lds = lds_wave_time;
-    wt.slot = 64u + (threadIdx.x >> 6);
-    if ((threadIdx.x & 63u) == 0u) lds_wave_time[wt.slot] = (unsigned int)__builtin_amdgcn_s_memtime();
-#endif
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (a.sample_begin > 0) {   // progressive continuation (samps.x protocol); s==0 resets (:451)
         const LaneCoords c = lane_coords();
@@ -1090,10 +1002,9 @@ __global__ void __launch_bounds__(256, (rounds_waves<Fast, Slab, NS>())) pathtra
         const uint32_t s = base + c.j;
         v3 q{0.0f, 0.0f, 0.0f};
         if (c.valid && s < a.sample_end) {
-            v3 rad = trace_sample<Fast, NP, NS, Slab, Prec, Box>(a, lds_obj, lds_emissive, hot, c.gx, c.gy, s, wt);
+            v3 rad = trace_sample<Fast, NP, NS, Slab, Prec, Box>(a, lds_obj, lds_emissive, hot, c.gx, c.gy, s);
             q = Fast ? rad * a.inv_spp : divs_recip<Fast>(rad, fspp, a.inv_spp);      // :452 accrad / samps.y (inv_spp = RN(1/spp), host)
         }
-        MC_WT(8);   // (idle tail of the round: lanes whose path ended wait for the longest one)
         // fold the round's S samples into the accumulator in sample order (every lane of the group
         // performs the same additions, so all S copies of acc stay identical)
         const uint32_t count = min((uint32_t)S, a.sample_end - base);           // wave-uniform
@@ -1112,13 +1023,6 @@ __global__ void __launch_bounds__(256, (rounds_waves<Fast, Slab, NS>())) pathtra
             }
         }
     }
-#ifdef MC_PT_WAVE_TIME
-    __syncthreads();
-    if (threadIdx.x < 32u) {
-        atomicAdd(&g_wave_time[threadIdx.x], (unsigned long long)lds_wave_time[threadIdx.x]);
-        atomicAdd(&g_wave_marks[threadIdx.x], (unsigned long long)lds_wave_time[32u + threadIdx.x]);
-    }
-#endif
     const LaneCoords c = lane_coords();
     const bool valid = c.valid;
     const uint32_t j = c.j;
