@@ -2,7 +2,8 @@
 """bench.py — headline benchmark of the hot path on MI355X (driver contract).
 
   python bench.py --gpus N --steps K --warmup W [--config K2|K1|K1ds|K3|K4]
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   — one rank per GPU;
+   the plain form `python bench.py --gpus N` starts exactly that launcher itself, as a CHILD process, and relays its one line)
 
 A "step" is one pass of the hot path over one synthetic batch (BASELINE.json configs):
   K2 (default, the headline): path trace 900 x 600, 500 spp, default scene.      WEAK scaling: image W x (600 N).
@@ -166,8 +167,55 @@ def parse():
     return a
 
 
+def profiler_preload():
+    """A profiler's preloaded library (rocprofv3 --pmc and friends) initialises the GPU before Python starts; every child this
+    process starts would then be an exec from a GPU-initialised process image, which this pool forbids."""
+    env = os.environ
+    if "rocprof" in env.get("LD_PRELOAD", "").lower():
+        return "LD_PRELOAD=" + env["LD_PRELOAD"]
+    for k in env:
+        if k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_TOOL_", "ROCTRACER_")):
+            return k
+    return None
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (the driver's N = 1 command shape): start the one-rank-per-GPU
+    launcher as a CHILD process — never os.exec*, and before this process has imported torch.cuda or made any HIP call — wait for
+    it, relay rank 0's single JSON line and the exit code."""
+    import socket
+    import subprocess
+    hint = (f"launch it as: python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+            f"--master-port <port> bench.py --gpus {args.gpus} ...")
+    why = profiler_preload()
+    if why:
+        sys.exit(f"bench.py --gpus {args.gpus}: a profiler preload is active ({why}); not starting the ranks from a process it has "
+                 f"initialised the GPU in — {hint} (the program after `--` must be the launcher itself)")
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this image
+    env["MC_BENCH_SPAWNED_BY"] = str(os.getpid())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)      # stderr passes through
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    for ln in p.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if p.returncode != 0:
+        sys.exit(f"bench.py --gpus {args.gpus}: the launcher exited with {p.returncode}" if p.returncode > 0 else p.returncode)
+    if len(lines) != 1:
+        sys.exit(f"bench.py --gpus {args.gpus}: expected one JSON line from rank 0, got {len(lines)}")
+    print(lines[0], flush=True)
+    return 0
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -181,9 +229,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n = args.gpus
-    if world != n:
-        if world == 1 and n > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != n:   # (N > 1 without a launcher never gets here: spawn_ranks)
         n = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback for the product path)")

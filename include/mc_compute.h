@@ -45,6 +45,10 @@ typedef struct mc_context mc_context; /* opaque: device, stream, scratch, LUT ca
 /* ---- lifecycle: replaces VulkanComputeApp::init() (vulkanComputeApp.cpp:443-449: createInstance,
  *      findPhysicalDevice, createDevice) and cleanupVulkanResources() (:673-695) -------------------- */
 int mc_abi_version(void);
+/* Which build is this: "pt=<id> mandel=<id> lib=<id>", each id 16 hex digits of the SHA-256 of the sources that kernel family (path
+ * tracer, Mandelbrot, whole library) was compiled from, and of the compiler flags.  Measurement records kept beside the code
+ * (profiles/ *_pmc_summary.json) carry the id of the library they were taken on; bench.py quotes them only for a matching build. */
+const char* mc_build_id(void);
 int mc_device_count(int* count);
 int mc_context_create(int device, mc_context** out_ctx);
 int mc_context_destroy(mc_context* ctx);
@@ -52,6 +56,22 @@ const char* mc_error_string(int status);
 const char* mc_last_error_detail(void);
 /* Device name / CU count of the context's device (vulkanComputeApp.cpp:163 picks devices[0]). */
 int mc_context_device_info(mc_context* ctx, char* name, size_t name_len, int* compute_units, int* clock_khz);
+
+/* Page-locked host memory for the storage buffer the application owns — what stands where the reference allocates its output buffer
+ * HOST_VISIBLE | HOST_COHERENT (VulkanComputeApp::createBuffer, vulkanComputeApp.cpp:489-533; mapped by getRenderedImage,
+ * mandelbrotApp.h:153 / pathtracerApp.h:206; freed at vulkanComputeApp.cpp:684-685).  The buffer lives in HBM while the kernels
+ * write it, so 16 B/pixel cross PCIe once, at the end of mc_*_render; into page-locked memory that copy needs no staging and no
+ * page pinning by the runtime.  Any host pointer is accepted by the render calls — a pageable one is copied at the same rate on this
+ * platform once its pages are resident (profiles/r05_d2h_probe.txt) — so these two are an ownership convention, not a requirement.
+ * Usable before any context exists; the memory is visible to every device of the node. */
+int mc_host_alloc(size_t bytes, void** out_ptr);
+int mc_host_free(void* ptr);
+
+/* Device time of the LAST blocking host-buffer call on this context (mc_mandelbrot_render, mc_pathtrace_render, mc_*_render_rgba8):
+ * kernel_ms = first launch to last kernel end (render, and the on-device conversion of the _rgba8 forms), copy_ms = the device -> host
+ * copy that follows.  HIP events on the context's stream; either pointer may be NULL.  MC_ERR_INVALID_ARGUMENT before the first such
+ * call.  (The reference times nothing, vulkanComputeApp.cpp:451-466 only prints progress; the apps print these next to run().) */
+int mc_context_last_timing(mc_context* ctx, double* kernel_ms, double* copy_ms);
 
 /* Shader clock (MHz) the device holds with every SIMD busy on fp32 VALU work, measured in-kernel (s_memtime against the
  * constant 100 MHz s_memrealtime over ~2 ms).  MI355X boxes differ by >10 % here (DVFS), and VALU-issue-bound kernels with
@@ -62,7 +82,7 @@ int mc_context_measure_clock(mc_context* ctx, double* sclk_mhz);
  *      MandelbrotApp::createCommandBuffer (src/mandelbrotApp.h:137-147) ----------------------------- */
 enum { MC_PRECISION_F32 = 0, MC_PRECISION_DS = 1 /* two-float, emulateDouble.h.glsl:59-139 */ };
 enum {
-    MC_MANDEL_FMA = 1u << 0,      /* NON-PARITY diagnostic: allow fp contraction in the fp32 loop */
+    /* bit 0 is a measurement switch of this repository (include/mc_compute_test.h), never set by a binding */
     MC_MANDEL_ITERS_U16 = 1u << 1 /* device form: d_iters is a uint16_t plane (max_iter <= 65535) — the multi-GPU exchange  */
                                   /* format, half of the 4-B plane and an eighth of the vec4 (mc_mandelbrot_assemble_...)  */
 };
@@ -109,23 +129,10 @@ enum {
     MC_PT_MATH_FAST = 1    /* gfx950 hardware rcp/rsq/sqrt/sin/cos/exp/log: toleranced parity    */
 };
 
-/* mc_pathtrace_params.flags — diagnostics.  In MC_PT_MATH_STRICT every accepted combination produces bit-identical buffers;
- * in MC_PT_MATH_FAST the kernels selected by different flags are different instruction sequences that agree within the
- * fast-math tolerance, and only the sample-parallel widths of ONE kernel are bit-identical to each other. */
-enum {
-    MC_PT_GENERIC_KERNEL = 1u << 0, /* never use the axis-aligned-slab specialisation of the plane test */
-    /* bit 1 is reserved (rounds 2-3: a lane-regrouping experiment, removed); reserved bits -> MC_ERR_INVALID_ARGUMENT */
-    MC_PT_NO_BOX_KERNEL = 1u << 2,  /* fast math: never use the closed-box specialisations (compile-time scene facts, the     */
-                                    /* sample-pool kernel); the general fast slab kernel runs instead (A/B measurements)      */
-    MC_PT_NO_POOL_KERNEL = 1u << 3, /* fast math: never use the sample-pool kernel (csrc/pathtrace_pool.h); the round-        */
-                                    /* synchronous closed-box kernel runs instead                                            */
-    MC_PT_SCENE_IN_LDS = 1u << 4,   /* generic scenes: every block stages the object records into LDS (the automatic choice   */
-    MC_PT_SCENE_IN_MEMORY = 1u << 5,/* for small scenes) / the kernel reads them where they lie (large scenes); strict math:  */
-                                    /* bit-identical either way                                                             */
-    MC_PT_NO_FAST_GUARD = 1u << 6   /* MEASUREMENTS only: run MC_PT_MATH_FAST even on a scene the host classifies as outside the */
-                                    /* fast tolerance (MC_PT_SCENE_LIGHT_ENCLOSED), which is otherwise rendered strict          */
-};
-#define MC_PT_FORCE_S(s) ((uint32_t)(s) << 8) /* force the sample-parallel width: 1, 4 or 16 (0 = automatic) */
+/* mc_pathtrace_params.flags: MC_PT_PRECISION(x) below (bits 16-19) is the one field a binding sets.  Bits 0-15 belong to this
+ * repository's measurement tools (kernel-selection A/B switches, include/mc_compute_test.h: not part of the boundary — a binding
+ * leaves them zero, and then every request is rendered by the kernel the host selects, inside the mode's parity contract);
+ * every other bit is reserved and refused with MC_ERR_INVALID_ARGUMENT. */
 /* Sphere-test precision branch of pathTracer.comp:132-256.  The reference compiles every variant OUT
  * (emulateDouble.h.glsl:13-26 are all FALSE) and enables one by hand together with the
  * TEST_PRECISION_WITH_LARGE_SPHERE_WALLS scene (pathtracerApp.h:11,28-35).  This DOES change results. */

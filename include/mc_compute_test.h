@@ -10,6 +10,31 @@
 extern "C" {
 #endif
 
+/* ---- measurement switches: bits of mc_mandelbrot_params.flags / mc_pathtrace_params.flags that libmc_compute.so honours for
+ *      this repository's tools (tools/, tests/: A/B timings, forced kernels, the unguarded fast kernels).  They are NOT part of
+ *      the boundary a reference maintainer binds (include/mc_compute.h offers precision, math mode, tiling and the sample
+ *      range — nothing that can leave a mode's parity contract); MC_PT_NO_FAST_GUARD in particular lets fast math run where it
+ *      cannot hold its tolerance.  In MC_PT_MATH_STRICT every accepted combination produces bit-identical buffers; in
+ *      MC_PT_MATH_FAST the kernels selected by different flags are different instruction sequences that agree within the
+ *      fast-math tolerance. */
+enum {
+    MC_MANDEL_FMA = 1u << 0       /* NON-PARITY: allow fp contraction in the fp32 Mandelbrot loop */
+};
+enum {
+    MC_PT_GENERIC_KERNEL = 1u << 0, /* never use the axis-aligned-slab specialisation of the plane test */
+    /* bit 1 is reserved (rounds 2-3: a lane-regrouping experiment, removed) */
+    MC_PT_NO_BOX_KERNEL = 1u << 2,  /* fast math: never use the closed-box specialisations (compile-time scene facts, the     */
+                                    /* sample-pool kernel); the general fast slab kernel runs instead                         */
+    MC_PT_NO_POOL_KERNEL = 1u << 3, /* never use the sample-pool kernel (csrc/pathtrace_pool.h); the round-synchronous        */
+                                    /* kernels run instead                                                                   */
+    MC_PT_SCENE_IN_LDS = 1u << 4,   /* generic scenes: every block stages the object records into LDS (the automatic choice   */
+    MC_PT_SCENE_IN_MEMORY = 1u << 5,/* for small scenes) / the kernel reads them where they lie (large scenes); strict math:  */
+                                    /* bit-identical either way                                                             */
+    MC_PT_NO_FAST_GUARD = 1u << 6   /* run MC_PT_MATH_FAST even on a scene the host classifies as outside the fast tolerance   */
+                                    /* (MC_PT_SCENE_LIGHT_ENCLOSED), which is otherwise rendered strict                   */
+};
+#define MC_PT_FORCE_S(s) ((uint32_t)(s) << 8) /* force the sample-parallel width: 1, 4 or 16 (0 = automatic) */
+
 /* fn: 0 mc_sin, 1 mc_cos, 2 mc_log2, 3 mc_exp2, 4 pow(x,0.45), 5 inversesqrt, 6 sqrt, 7 1/x,
  * 8/9 sin/cos via the fused mc_sincos; fast=1 evaluates the MC_PT_MATH_FAST variants instead. */
 int mc_test_math(mc_context* ctx, int fn, int fast, const float* in, float* out, size_t n);

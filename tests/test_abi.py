@@ -32,6 +32,30 @@ def test_test_hooks_live_in_their_own_library(B):
     assert not [n for n in B.declared_symbols() if n.startswith("mc_test_")]
 
 
+def test_public_header_offers_no_measurement_switch(B, tmp_path):
+    """the header a reference maintainer binds offers precision, math mode, tiling and the sample
+    range — none of this repository's A/B switches (forced kernels, the unguarded fast kernels, the contracting Mandelbrot), which
+    live with the test hooks in include/mc_compute_test.h under the same bit values the library honours for tools/ and tests/."""
+    import re
+    pub = re.sub(r"/\*.*?\*/", "", open(B.HEADER_PATH).read(), flags=re.S)
+    switches = ["MC_PT_GENERIC_KERNEL", "MC_PT_NO_BOX_KERNEL", "MC_PT_NO_POOL_KERNEL", "MC_PT_NO_FAST_GUARD", "MC_PT_FORCE_S",
+                "MC_PT_SCENE_IN_LDS", "MC_PT_SCENE_IN_MEMORY", "MC_MANDEL_FMA"]
+    assert not [w for w in switches if w in pub]
+    assert "mc_compute_test.h" not in pub and "mc_debug" not in pub
+    diag = open(B.TEST_HEADER_PATH).read()
+    assert not [w for w in switches if w not in diag]
+    # same bit values as the Python mirror the tools use; the test header is plain C too
+    src = tmp_path / "flags.c"
+    src.write_text('#include <stdio.h>\n#include "mc_compute_test.h"\nint main(void){printf("%u %u %u %u %u %u %u %u %u\\n", (unsigned)MC_MANDEL_FMA,'
+                   '(unsigned)MC_PT_GENERIC_KERNEL, (unsigned)MC_PT_NO_BOX_KERNEL, (unsigned)MC_PT_NO_POOL_KERNEL, (unsigned)MC_PT_SCENE_IN_LDS,'
+                   '(unsigned)MC_PT_SCENE_IN_MEMORY, (unsigned)MC_PT_NO_FAST_GUARD, (unsigned)MC_PT_FORCE_S(16), (unsigned)MC_MANDEL_ITERS_U16);return 0;}\n')
+    exe = tmp_path / "flags"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got == [B.MANDEL_FMA, B.PT_GENERIC_KERNEL, B.PT_NO_BOX_KERNEL, B.PT_NO_POOL_KERNEL, B.PT_SCENE_IN_LDS, B.PT_SCENE_IN_MEMORY,
+                   B.PT_NO_FAST_GUARD, B.pt_force_s(16), B.MANDEL_ITERS_U16]
+
+
 def test_param_struct_layouts(B, tmp_path):
     """The header is plain C (gcc -std=c99 compiles it) and the ctypes mirrors have the compiler's layout."""
     src = tmp_path / "layout.c"

@@ -125,3 +125,21 @@ def test_sharding_helpers(B):
     assert (p.row_begin, p.row_end, p.row_block, p.row_stride) == (0, 600, 0, 0)
     with pytest.raises(RuntimeError):
         S.assemble_device(None, torch.zeros(1, 2, 2, 4), 2, 2, 1, torch.zeros(2, 2, 4))
+
+
+def test_plain_bench_command_starts_one_rank_per_gpu_as_a_child_process():
+    """The driver's plain command shape with --gpus N > 1: bench.py starts the launcher itself, as a child,
+    before it touches the GPU, and relays the outcome.  Without a GPU here the ranks it started fail loudly ("no HIP device visible":
+    there is no CPU fallback) — seen once per rank, so both ranks ran — and the launcher's failure is this command's exit code; under a
+    profiler's preload nothing is started and the launcher line is the hint."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: tests/test_gpu_bench_contract.py runs the real thing")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and not p.stdout.strip()
+    assert p.stderr.count("no HIP device visible") == 2 and "the launcher exited with" in p.stderr
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=dict(env, ROCPROFILER_TEST_MARK="1"),
+                       capture_output=True, text=True, timeout=60)
+    assert p.returncode != 0 and "torch.distributed.run" in p.stderr and "no HIP device" not in p.stderr

@@ -75,6 +75,26 @@ def test_two_rank_rehearsal_is_bit_identical_to_one_gpu():
     assert "cpu_baseline" not in d                      # rank 0 at N = 1 only
 
 
+def test_plain_command_with_two_gpus_starts_its_own_ranks():
+    """the driver's N = 1 command shape with --gpus 2 — no launcher around it — must not die on the launcher:
+    bench.py starts `torch.distributed.run` as a child process before touching the GPU and relays rank 0's one line (gloo rehearsal
+    on the one GPU; every rank saw world size 2; --verify: the gathered image equals the single-GPU render)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--spp", "16", "--verify"],
+                       cwd=ROOT, env=dict(env, MC_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]
+    d = json.loads(lines[0])
+    check_common(d, 2, 1, 1)
+    c = d["config"]
+    assert c["world_size"] == 2 and [r["world_size_seen"] for r in c["ranks"]] == [2, 2] and c["verified_equal_to_single_gpu"] is True
+    # under a profiler's preload it refuses, with the launcher line as the hint, before any child is started
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--spp", "16"],
+                       cwd=ROOT, env=dict(env, ROCPROFILER_TEST_MARK="1"), capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "torch.distributed.run" in p.stderr and not p.stdout.strip()
+
+
 def test_baseline_8gpu_configs_run_from_the_driver_command():
     """BASELINE's 8-GPU configurations are reachable as `bench.py --config K3|K4` (strong scaling: the whole image on N
     ranks).  K4 at full size on one GPU; K3 at reduced spp (its 4096-spp step is 4e10 samples, ~4 s)."""

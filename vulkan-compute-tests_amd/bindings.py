@@ -104,6 +104,12 @@ def lib():
         L.mc_pathtrace_render_device_async.argtypes = [vp, C.POINTER(PathtraceParams), vp, u32, vp, u32, vp, vp]
         L.mc_convert_rgba8_device_async.argtypes = [vp, vp, u32, u32, f32, i32, vp, vp]
         L.mc_convert_rgba8.argtypes = [vp, vp, u32, u32, f32, i32, vp]
+        if hasattr(L, "mc_build_id"):   # (a diagnostic build older than round 5, loaded through MC_LIB_PATH, lacks these four)
+            L.mc_build_id.restype = C.c_char_p
+            L.mc_build_id.argtypes = []
+            L.mc_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+            L.mc_host_free.argtypes = [vp]
+            L.mc_context_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.mc_multi_create.argtypes = [i32, C.POINTER(vp)]
         L.mc_multi_destroy.argtypes = [vp]
         L.mc_multi_mandelbrot_render.argtypes = [vp, C.POINTER(MandelbrotParams), vp, vp]
@@ -228,6 +234,33 @@ def pathtrace_select_kernel(p, planes=None, spheres=None):
     return out
 
 
+def build_id():
+    """mc_build_id as a dict: {"pt": ..., "mandel": ..., "lib": ...} (source hashes of the loaded library's kernel families)."""
+    return dict(kv.split("=") for kv in lib().mc_build_id().decode().split())
+
+
+class HostBuffer:
+    """Page-locked host memory from mc_host_alloc, exposed as a numpy array (the storage buffer an application owns)."""
+
+    def __init__(self, shape, dtype=np.float32):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = C.c_void_p()
+        _check(lib().mc_host_alloc(self.nbytes, C.byref(self._p)), "mc_host_alloc")
+        self.array = np.frombuffer((C.c_char * self.nbytes).from_address(self._p.value), dtype=dtype).reshape(shape)
+
+    def free(self):
+        if self._p:
+            self.array = None
+            _check(lib().mc_host_free(self._p), "mc_host_free")
+            self._p = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.free()
+
+
 def pathtrace_scene_class(planes, spheres):
     """mc_pathtrace_scene_class: which kernel specialisations the host would select for this scene (no device needed)."""
     planes = np.ascontiguousarray(planes, np.float32).reshape(-1, 12)
@@ -279,21 +312,28 @@ class Context:
     def synchronize(self):
         _check(lib().mc_context_synchronize(self._h), "mc_context_synchronize")
 
+    def last_timing(self):
+        """(kernel_ms, copy_ms) of the last blocking host-buffer call on this context (mc_context_last_timing)."""
+        k, c = C.c_double(0.0), C.c_double(0.0)
+        _check(lib().mc_context_last_timing(self._h, C.byref(k), C.byref(c)), "mc_context_last_timing")
+        return k.value, c.value
+
     # ---- host-buffer forms -------------------------------------------------------------------------
-    def mandelbrot(self, p, want_rgba=True, want_iters=True):
+    def mandelbrot(self, p, want_rgba=True, want_iters=True, out=None):
         rows = tile_rows(p)
-        rgba = np.empty((rows, p.width, 4), np.float32) if want_rgba else None
+        rgba = (out if out is not None else np.empty((rows, p.width, 4), np.float32)) if want_rgba else None
         iters = np.empty((rows, p.width), np.uint32) if want_iters else None
         _check(lib().mc_mandelbrot_render(self._h, C.byref(p), _ptr(rgba), _ptr(iters)), "mc_mandelbrot_render")
         return rgba, iters
 
-    def pathtrace(self, p, planes=None, spheres=None, acc=None):
+    def pathtrace(self, p, planes=None, spheres=None, acc=None, out=None):
         if planes is None or spheres is None:
             planes, spheres = default_scene()
         planes = np.ascontiguousarray(planes, np.float32).reshape(-1)
         spheres = np.ascontiguousarray(spheres, np.float32).reshape(-1)
         rows = tile_rows(p)
-        out = np.zeros((rows, p.width, 4), np.float32) if acc is None else np.ascontiguousarray(acc, np.float32).copy()
+        if out is None:   # (out: the caller's own buffer, e.g. HostBuffer.array — written in place)
+            out = np.zeros((rows, p.width, 4), np.float32) if acc is None else np.ascontiguousarray(acc, np.float32).copy()
         _check(lib().mc_pathtrace_render(self._h, C.byref(p), _ptr(planes), planes.size // 12, _ptr(spheres),
                                          spheres.size // 12, _ptr(out)), "mc_pathtrace_render")
         return out

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/mc_compute.h"
+#include "../../include/mc_compute_test.h"   // the measurement switches the library honours for tools/ and tests/ (flag bits only)
 
 namespace mc {
 
@@ -62,6 +63,11 @@ struct mc_context {
     mc::DeviceBuffer status;
     int ensure_status();
     int check_status();   // call after the stream is idle: MC_OK, or MC_ERR_HIP with a detail message
+    // The blocking host-buffer entry points bracket their kernel launches and their device -> host copy with events on the context's
+    // stream (mc_context_last_timing): t[0] before the first launch, t[1] after the last kernel, t[2] after the copy.
+    hipEvent_t t_ev[3] = {nullptr, nullptr, nullptr};
+    bool timing_valid = false;
+    int mark(int k);      // records t_ev[k] on the context's stream (creating the events on first use)
 };
 
 namespace mc {

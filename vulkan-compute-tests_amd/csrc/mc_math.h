@@ -83,6 +83,24 @@ __device__ __forceinline__ float div_step(float a, float s, float y) {
     return __builtin_fmaf(r, y, q0);
 }
 
+// Fork census (tools/fork_census.py; measurement builds only, `make exp EXP_FLAGS=-D...=1`): the fast mode's hardware seeds replaced by
+// the correctly rounded operations (MC_PT_FAST_IEEE: v_rcp / v_rsq / v_sqrt -> IEEE divide, sqrt, 1/sqrt) or its hardware sine / cosine
+// by the strict mode's Cody-Waite + cephes pair (MC_PT_FAST_ACCURATE_SINCOS), everything else of fast math left as it is — which
+// approximation carries how many of the forked samples (profiles/r05_fork_census.txt).
+#ifndef MC_PT_FAST_IEEE
+#define MC_PT_FAST_IEEE 0
+#endif
+#ifndef MC_PT_FAST_ACCURATE_SINCOS
+#define MC_PT_FAST_ACCURATE_SINCOS 0
+#endif
+// MC_PT_FAST_SHORT: the fast mode's division, square root and reciprocal square root ROUNDED AS THE REFERENCE ROUNDS THEM — the short
+// forms of the strict mode (one hardware seed + 3 .. 7 ordinary instructions; correct rounding enumerated over every fp32 pattern of
+// their windows, see sqrt_short / rcp_short / div_step / rsqrt_short below), without the strict mode's window tests: outside the windows
+// (denormal, infinite, NaN arguments — no finite path produces one) the result is merely inaccurate, and the one argument a path does
+// produce there, an exact zero under a square root, is selected per lane.
+#ifndef MC_PT_FAST_SHORT
+#define MC_PT_FAST_SHORT 0
+#endif
 #ifdef MC_EXPERIMENT_NO_TRANS
 // MEASUREMENT BUILD ONLY (make exp EXP_FLAGS=-DMC_EXPERIMENT_NO_TRANS; tools/pmc_libs.sh): the fast kernels' hardware transcendentals
 // replaced by ordinary-instruction approximations (bit-pattern seeds + two Newton steps; a parabola pair for sin / cos) good to ~1e-3 —
@@ -110,7 +128,8 @@ template <bool Fast> __device__ __forceinline__ float fdiv(float a, float b) {
 #ifdef MC_EXPERIMENT_NO_TRANS
     if (Fast) return a * nt_rcp(b);
 #endif
-    if (Fast) return a * __builtin_amdgcn_rcpf(b);
+    if (Fast && MC_PT_FAST_SHORT) return div_step(a, b, rcp_short(b));
+    if (Fast && !MC_PT_FAST_IEEE) return a * __builtin_amdgcn_rcpf(b);
     return ieee_div(a, b);
 }
 // (a0, a1, a2) / s.  Strict: the short division inside its window (wave-wide test), the compiler's IEEE expansion outside.
@@ -135,7 +154,9 @@ template <bool Fast> __device__ __forceinline__ float fsqrt(float a) {
 #ifdef MC_EXPERIMENT_NO_TRANS
     if (Fast) return a * nt_rsq(a);
 #endif
-    if (Fast) return __builtin_amdgcn_sqrtf(a);
+    if (Fast && MC_PT_FAST_SHORT) { const float r = sqrt_short(a); return a == 0.0f ? 0.0f : r; }
+    if (Fast && !MC_PT_FAST_IEEE) return __builtin_amdgcn_sqrtf(a);
+    if (Fast) return ieee_sqrt(a);
 #ifdef MC_EXPERIMENT_NO_WINDOW_GUARD   // measurement only: what the per-call window tests cost (NOT exact outside the window)
     return sqrt_short(a);
 #endif
@@ -146,7 +167,9 @@ template <bool Fast> __device__ __forceinline__ float inversesqrt(float a) {
 #ifdef MC_EXPERIMENT_NO_TRANS
     if (Fast) return nt_rsq(a);
 #endif
-    if (Fast) return __builtin_amdgcn_rsqf(a);
+    if (Fast && MC_PT_FAST_SHORT) return rsqrt_short(a);
+    if (Fast && !MC_PT_FAST_IEEE) return __builtin_amdgcn_rsqf(a);
+    if (Fast) return ieee_div(1.0f, ieee_sqrt(a));
 #ifdef MC_EXPERIMENT_NO_WINDOW_GUARD
     return rsqrt_short(a);
 #endif
@@ -208,7 +231,9 @@ template <bool Fast> __device__ __forceinline__ void sincos_angle(float angle, f
 #ifdef MC_EXPERIMENT_NO_TRANS
     if (Fast) { s = nt_sin_rev(u); c = nt_sin_rev(u + 0.25f); return; }
 #endif
-    if (Fast) {
+    if (Fast && MC_PT_FAST_ACCURATE_SINCOS) {   // (census build; a caller of the fast form may pass angle = 0: formed here)
+        mc_sincos(6.283185307179586f * u, s, c);
+    } else if (Fast) {
         // v_sin_f32 / v_cos_f32 take revolutions: sin(2*pi*u).  u in [0,1].
         s = __builtin_amdgcn_sinf(u);
         c = __builtin_amdgcn_cosf(u);

@@ -36,6 +36,15 @@
 #include "ds_arith.h"
 #include "mc_math.h"
 
+// Fork census only (tools/fork_census.py, profiles/r05_fork_census.txt): the sampled / refracted directions re-normalised as the
+// reference does (:413, :428, :441); the root form of the shadow test although the spheres are disjoint
+#ifndef MC_PT_FAST_RENORMALISE
+#define MC_PT_FAST_RENORMALISE 0
+#endif
+#ifndef MC_PT_FAST_NO_DISJOINT
+#define MC_PT_FAST_NO_DISJOINT 0
+#endif
+
 namespace mc {
 namespace pt {
 
@@ -141,7 +150,7 @@ template <bool Fast> __device__ __forceinline__ v3 tangent_u(v3 w) {
 // :413 and :428).  Strict: the literal normalize.  Fast (toleranced): the vector is already of unit length to within the
 // accuracy of v_sin/v_cos/v_sqrt (~1e-6), which is what the rescaling would remove; it is used as it is.
 template <bool Fast, bool UnitBasis> __device__ __forceinline__ v3 normalize_unit_combination(v3 a) {
-    if constexpr (Fast && UnitBasis) return a;
+    if constexpr (Fast && UnitBasis && !MC_PT_FAST_RENORMALISE) return a;
     else return normalize<Fast>(a);
 }
 // reflect(I,N) = I - 2*dot(N,I)*N
@@ -643,11 +652,15 @@ template <bool Fast> __device__ __forceinline__ v3 light_sample_direction(v3 xc,
             const float sp = __builtin_fmaf(b, B, c * m);
             const float sa = sel ? a : -a;
             const float first = __builtin_fmaf(sa, sw.z, q * cm), lz = __builtin_fmaf(-sa, q, sw.z * cm);
-            return v3{sel ? first : sp, sel ? sp : first, lz};                // :413
+            const v3 lv{sel ? first : sp, sel ? sp : first, lz};              // :413
+            if constexpr (MC_PT_FAST_RENORMALISE != 0) return normalize<true>(lv);
+            return lv;
         }
         const v3 t1{sel ? sw.z : 0.0f, sel ? 0.0f : -sw.z, sel ? -q : q};
         const v3 t2 = cross(sw, t1);
-        return (t1 * (cphi * g) + t2 * (sphi * g)) + sw * cos_a;              // :413
+        const v3 lv = (t1 * (cphi * g) + t2 * (sphi * g)) + sw * cos_a;       // :413
+        if constexpr (MC_PT_FAST_RENORMALISE != 0) return normalize<true>(lv);
+        return lv;
     }
     v3 su = tangent_u<Fast>(sw);
     v3 sv = cross(sw, su);
@@ -659,7 +672,7 @@ template <bool Fast> __device__ __forceinline__ v3 light_sample_direction(v3 xc,
     float sphi, cphi;
     dm::sincos_angle<Fast>(phi, rnd.y, sphi, cphi);
     // fast: the two scalar factors of a tangent are multiplied first (u*(c*s) for (u*c)*s: one product less per component)
-    return Fast ? (su * (cphi * sin_a) + sv * (sphi * sin_a)) + sw * cos_a
+    return Fast ? normalize_unit_combination<Fast, true>((su * (cphi * sin_a) + sv * (sphi * sin_a)) + sw * cos_a)
                 : normalize_unit_combination<Fast, true>(((su * cphi) * sin_a + (sv * sphi) * sin_a) + sw * cos_a);   // :413
 }
 // Cosine-weighted bounce around w = nl (:426-:428).  Unit: w is of unit length (slab kernels: +-1 axis normals, normalised sphere
@@ -720,7 +733,9 @@ __device__ __forceinline__ v3 specular_bounce_fast(int mat, v3 rd, v3 n, float d
             if (!pick_refl) { alpha = nnt; beta = -k; }
         }
     }
-    return rd * alpha + n * beta;
+    const v3 out = rd * alpha + n * beta;
+    if constexpr (MC_PT_FAST_RENORMALISE != 0) return normalize<true>(out);
+    return out;
 }
 
 // Mirror / glass bounce in the general form (:432-:447) — the strict kernels (literal operation order) and the fast generic
@@ -880,7 +895,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
                 bool reached;                                             // :420 shadow ray: is the nearest hit sphere i?
                 if constexpr (Slab) {
                     // (closed-box kernel, disjoint spheres — a uniform scene fact: the root-free test of the sample-pool kernel)
-                    if (Box && sc.spheres_disjoint != 0u) reached = shadow_visible_disjoint<false>(hot, l, i, xoc, occ);
+                    if (Box && sc.spheres_disjoint != 0u && !MC_PT_FAST_NO_DISJOINT) reached = shadow_visible_disjoint<false>(hot, l, i, xoc, occ);
                     else if (Box || sc.nee_skip_planes != 0u) reached = shadow_reaches_sphere<Fast>(hot, x, l, i, xc, occ);
                     else reached = intersect_slab<Fast>(hot, x, l, tne, false) == np + i;
                 } else {

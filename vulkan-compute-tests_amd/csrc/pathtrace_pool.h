@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_
 template <bool Fast, int S, int NS> inline int launch_pool_one(const PTArgs& a, uint32_t tile_rows, hipStream_t s) {
     dim3 grid((a.W + block_w<S>() - 1u) / block_w<S>(), (tile_rows + block_h<S>() - 1u) / block_h<S>());
     constexpr size_t lds = pool_block_lds_bytes<Fast, NS>();
-    if (Fast && !a.scene.spheres_disjoint) hipLaunchKernelGGL((pathtrace_pool_kernel<Fast, S, NS, false>), grid, dim3(256), lds, s, a);
+    if (Fast && (!a.scene.spheres_disjoint || MC_PT_FAST_NO_DISJOINT)) hipLaunchKernelGGL((pathtrace_pool_kernel<Fast, S, NS, false>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((pathtrace_pool_kernel<Fast, S, NS, true>), grid, dim3(256), lds, s, a);
     return MC_OK;
 }

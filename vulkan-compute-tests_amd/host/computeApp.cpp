@@ -2,7 +2,9 @@
 
 #include "pngWriter.h"
 
+#include <algorithm>
 #include <chrono>
+#include <thread>
 
 ComputeApp::~ComputeApp() {
     // cleanupVulkanResources (vulkanComputeApp.cpp:673-695)
@@ -35,7 +37,50 @@ void ComputeApp::init() {
     }
 }
 
-void ComputeApp::createBuffer(uint64_t bufferSizeBytes) { buffer.assign(bufferSizeBytes / sizeof(float), 0.0f); }
+void HostStorage::allocate(uint64_t bytes) {
+    release();
+    void* p = nullptr;
+    const int rc = mc_host_alloc((size_t)bytes, &p);
+    if (rc != MC_OK) {
+        std::string msg = std::string("mc_host_alloc: ") + mc_error_string(rc);
+        const char* d = mc_last_error_detail();
+        if (d && d[0]) msg += std::string(" (") + d + ")";
+        throw std::runtime_error(msg);
+    }
+    ptr_ = static_cast<float*>(p);
+    floats_ = (size_t)(bytes / sizeof(float));
+}
+
+void ComputeApp::createBuffer(uint64_t bufferSizeBytes) {
+    auto t0 = std::chrono::steady_clock::now();
+    buffer.allocate(bufferSizeBytes);
+    times.allocMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void ComputeApp::convertStorage(std::vector<uint8_t>& image, uint32_t resx, uint32_t resy, float scale, bool rotate180) const {
+    struct Pixel { float r, g, b, a; };
+    const Pixel* p = reinterpret_cast<const Pixel*>(buffer.data());
+    image.resize((size_t)resx * resy * 4);
+    uint8_t* out = image.data();
+    // Destination pixel of source pixel (x, y) under the reference's swap loop: every pixel with x < resx / 2 changes places with its
+    // point reflection; for an odd width the middle column (x = resx / 2) is left where it is (pathtracerApp.h:238: `x < resx / 2`).
+    auto rows = [&](uint32_t y0, uint32_t y1) {
+        for (uint32_t y = y0; y < y1; y++)
+            for (uint32_t x = 0; x < resx; x++) {
+                const Pixel& s = p[(size_t)y * resx + x];
+                size_t to = (size_t)y * resx + x;
+                if (rotate180 && !((resx & 1u) && x == resx / 2)) to = (size_t)(resy - 1 - y) * resx + (resx - 1 - x);
+                uint8_t* o = out + 4 * to;
+                o[0] = x86FloatToU8(scale * s.r); o[1] = x86FloatToU8(scale * s.g); o[2] = x86FloatToU8(scale * s.b); o[3] = 255u;
+            }
+    };
+    unsigned n = pngThreads > 0 ? (unsigned)pngThreads : std::thread::hardware_concurrency();
+    n = std::max(1u, std::min(n, std::max(1u, resy / 16u)));
+    if (n == 1) { rows(0, resy); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < n; t++) th.emplace_back(rows, (uint32_t)((uint64_t)resy * t / n), (uint32_t)((uint64_t)resy * (t + 1) / n));
+    for (auto& t : th) t.join();
+}
 
 void ComputeApp::run() {
     if (!quiet) { printf("in run()\n"); fflush(stdout); }
@@ -44,6 +89,9 @@ void ComputeApp::run() {
     runCommandBuffer();
     auto t1 = std::chrono::steady_clock::now();
     lastRunMs = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    times.runMs = lastRunMs;
+    times.kernelMs = times.copyMs = 0.0;
+    if (ctx) (void)mc_context_last_timing(ctx, &times.kernelMs, &times.copyMs);
     if (!quiet) { printf("run() finished in %.3f ms\n", lastRunMs); fflush(stdout); }
 }
 

@@ -20,6 +20,28 @@
 
 #include "mc_compute.h"
 
+// The storage buffer's host side: page-locked memory from mc_host_alloc — what stands where the reference allocates its output
+// buffer HOST_VISIBLE | HOST_COHERENT and maps it (vulkanComputeApp.cpp:489-533, mandelbrotApp.h:153, pathtracerApp.h:206).
+class HostStorage {
+public:
+    HostStorage() = default;
+    HostStorage(const HostStorage&) = delete;
+    HostStorage& operator=(const HostStorage&) = delete;
+    ~HostStorage() { release(); }
+    void allocate(uint64_t bytes);             // throws std::runtime_error; the contents are unspecified until run() has filled them
+    void release() { if (ptr_) mc_host_free(ptr_); ptr_ = nullptr; floats_ = 0; }
+    float* data() { return ptr_; }
+    const float* data() const { return ptr_; }
+    size_t size() const { return floats_; }    // in floats
+    bool empty() const { return floats_ == 0; }
+    const float* begin() const { return ptr_; }
+    const float* end() const { return ptr_ + floats_; }
+    float operator[](size_t i) const { return ptr_[i]; }
+private:
+    float* ptr_ = nullptr;
+    size_t floats_ = 0;
+};
+
 struct ComputeApp {
     virtual ~ComputeApp();
 
@@ -41,13 +63,18 @@ struct ComputeApp {
     // float->u8 conversion (+ rotation) on the device so only RGBA8 crosses PCIe; the fp32 storage buffer is then
     // not copied to the host (storageBuffer() stays empty).  Same cast semantics, same bytes.
     void setGpuPostprocess(bool g) { gpuPostprocess = g; }
-    void setPngThreads(int t) { pngThreads = t; }   // 0 = all cores, 1 = serial deflate
+    void setPngThreads(int t) { pngThreads = t; }   // 0 = all cores, 1 = serial deflate; the host float -> u8 loop uses the same count
     // saveRenderedImage's file: a standard PNG of exactly the RGBA8 pixels the reference converts its buffer to (mandelbrotApp.h:159-174,
     // pathtracerApp.h:202-243), deflated stripe-parallel by pngWriter.h.  The reference encodes the same pixels with its vendored
     // third-party codec (lodepng::encode, mandelbrotApp.h:181 / pathtracerApp.h:245): a reference tree that calls this library
     // (INTEGRATION.md route B) keeps that call and therefore its exact bytes; the standalone apps do not re-implement that codec.
     std::string writePng(const char* filename, const uint8_t* rgba8, uint32_t w, uint32_t h) const;
     double lastRunMilliseconds() const { return lastRunMs; }
+    // Where the time of the last run() / saveRenderedImage() went (milliseconds; SURVEY §8d "end-to-end ... reported separately"):
+    // device time of the kernels and of the device -> host copy (mc_context_last_timing; 0 for multi-GPU runs), the host
+    // float -> u8 (+ rotation) loop, the PNG encoder + file write.
+    struct Timing { double allocMs = 0, runMs = 0, kernelMs = 0, copyMs = 0, convertMs = 0, pngMs = 0; };
+    const Timing& timing() const { return times; }
 
 protected:
     void createBuffer(uint64_t bufferSizeBytes);   // vulkanComputeApp.cpp:489-533: the output storage buffer
@@ -62,9 +89,15 @@ protected:
     int pngThreads = 0;
     std::vector<uint8_t> rgba8;   // filled by run() when gpuPostprocess is on
     double lastRunMs = 0.0;
+    Timing times;
     // The storage buffer, host side: vec4 fp32 per pixel, row-major (what vkMapMemory exposes to
     // getRenderedImage in the reference).
-    std::vector<float> buffer;
+    HostStorage buffer;
+    // getRenderedImage's loop (mandelbrotApp.h:159-166, pathtracerApp.h:212-219) over row stripes on `pngThreads` host threads
+    // (0 = all): u8 = static_cast<uint8_t>(scale * c) with the reference binary's x86-64 semantics, alpha 255; rotate180 = the path
+    // tracer's swap loop (pathtracerApp.h:236-243, incl. its odd-width middle column) applied while writing.  Same bytes as the
+    // serial loops, which tests/test_gpu_output.py holds them to.
+    void convertStorage(std::vector<uint8_t>& image, uint32_t resx, uint32_t resy, float scale, bool rotate180) const;
 };
 
 // Drop-in alias: code written against the reference's base-class name keeps compiling.

@@ -29,7 +29,7 @@ int main(int argc, char* argv[]) {
     // split options from positional arguments
     std::vector<const char*> pos;
     int gpus = 1;
-    bool quiet = false, gpuPost = false;
+    bool quiet = false, gpuPost = false, timingJson = false;
     int pngThreads = 0;
     const char* outFile = nullptr;
     uint32_t width = 2000, height = 2000, maxIter = 128, precision = MC_PRECISION_F32, mathMode = MC_PT_MATH_STRICT;
@@ -44,7 +44,10 @@ int main(int argc, char* argv[]) {
         else if (a == "--quiet") quiet = true;
         else if (a == "--gpu-postprocess") gpuPost = true;     // float->u8 (+rotation) on the device, RGBA8-only download
         else if (a == "--png-threads") { need(1); pngThreads = atoi(argv[++i]); }   // 0 = all cores (default), 1 = serial
-        else if (a == "--fast-png") {}                         // (accepted for round-3 command lines: the parallel writer is the only one)
+        else if (a == "--timing-json") timingJson = true;      // one JSON line: where the wall time of this run went (bench.py end_to_end)
+        else if (a == "--fast-png")                             // (round-3 command lines: the stripe-parallel writer is the only one now)
+            printf("note: --fast-png has no effect — the apps always write their own standard PNG (identical pixels; the reference "
+                   "codec's exact file bytes come from a reference tree that calls this library, INTEGRATION.md route B)\n");
         else if (a == "--width") { need(1); width = (uint32_t)atoi(argv[++i]); }
         else if (a == "--height") { need(1); height = (uint32_t)atoi(argv[++i]); }
         else if (a == "--max-iter") { need(1); maxIter = (uint32_t)atoi(argv[++i]); }
@@ -80,10 +83,13 @@ int main(int argc, char* argv[]) {
     app.setGpuPostprocess(gpuPost);
     app.setPngThreads(pngThreads);
 
+    const auto tStart = std::chrono::steady_clock::now();
+    auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     try {
         // the reference calls init()/preRun() outside its try block (main.cpp:28-29); a missing device
         // then terminates via an uncaught exception.  Kept inside here so the failure is reported.
         app.init();
+        const double initMs = since(tStart);
         app.preRun();
         printf("now running app!\n");
         app.run();
@@ -92,6 +98,14 @@ int main(int argc, char* argv[]) {
         else app.saveRenderedImage();
         double saveMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (!quiet) printf("saveRenderedImage() finished in %.3f ms\n", saveMs);
+        if (timingJson) {   // init = context creation (HIP start-up); alloc = the pinned storage buffer; run = the blocking render call, of
+                            // which kernel + copy are device time; convert = float -> u8 (+ rotation) on the host (0: done on the device);
+                            // png = encode + write; total = process wall time up to here
+            const ComputeApp::Timing& t = app.timing();
+            printf("{\"timing_ms\": {\"init\": %.3f, \"alloc\": %.3f, \"run\": %.3f, \"kernel\": %.3f, \"copy\": %.3f, \"convert\": %.3f, "
+                   "\"png\": %.3f, \"total\": %.3f}, \"gpu_postprocess\": %s, \"gpus\": %d}\n",
+                   initMs, t.allocMs, t.runMs, t.kernelMs, t.copyMs, t.convertMs, t.pngMs, since(tStart), gpuPost ? "true" : "false", gpus);
+        }
     } catch (const std::runtime_error& e) {
         printf("%s\n", e.what());
         return EXIT_FAILURE;

@@ -2,6 +2,8 @@
 #ifndef MANDELBROTAPP_H_
 #define MANDELBROTAPP_H_
 
+#include <chrono>
+
 #include "computeApp.h"
 #include "pngWriter.h"
 
@@ -52,27 +54,24 @@ struct MandelbrotApp : public ComputeApp {
     // mandelbrotApp.h:149-170: u8 = static_cast<uint8_t>(scale * c), alpha 255.  The cast is UB out of
     // range; the reference binary on x86-64 truncates to int32 and keeps the low byte — stated explicitly.
     void getRenderedImage(std::vector<uint8_t>& image, const uint32_t resx, const uint32_t resy, float floatScaleFactor) {
-        const Pixel* p = reinterpret_cast<const Pixel*>(buffer.data());
-        image.resize((size_t)resx * resy * 4);
-        for (size_t i = 0; i < (size_t)resx * resy; i++) {
-            image[4 * i + 0] = x86FloatToU8(floatScaleFactor * p[i].r);
-            image[4 * i + 1] = x86FloatToU8(floatScaleFactor * p[i].g);
-            image[4 * i + 2] = x86FloatToU8(floatScaleFactor * p[i].b);
-            image[4 * i + 3] = 255u;
-        }
+        convertStorage(image, resx, resy, floatScaleFactor, false);   // the loop of :159-166, row stripes in parallel
     }
 
     virtual void saveRenderedImage(const char* png_filename = "mandelbrot.png") override {
         std::vector<uint8_t> image;
         constexpr float scaleFactor = 255.0f;   // mandelbrotApp.h:174
+        auto t0 = std::chrono::steady_clock::now();
         if (gpuPostprocess) image.swap(rgba8);  // already converted on the device with the same cast semantics
         else getRenderedImage(image, resx, resy, scaleFactor);
+        auto t1 = std::chrono::steady_clock::now();
         printf("writing %s\n", png_filename);
         std::string err = writePng(png_filename, image.data(), resx, resy);
         if (!err.empty()) printf("encoder error: %s", err.c_str());   // printed, not thrown (mandelbrotApp.h:183)
+        times.convertMs = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        times.pngMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
     }
 
-    const std::vector<float>& storageBuffer() const { return buffer; }
+    const HostStorage& storageBuffer() const { return buffer; }
 
 private:
     struct Pixel { float r, g, b, a; };   // mandelbrotApp.h:187-189

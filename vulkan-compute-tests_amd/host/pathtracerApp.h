@@ -2,6 +2,7 @@
 #ifndef PATHTRACERAPP_H_
 #define PATHTRACERAPP_H_
 
+#include <chrono>
 #include <cstring>
 
 #include "computeApp.h"
@@ -98,39 +99,30 @@ struct PathtracerApp : public ComputeApp {
 
     // pathtracerApp.h:202-223
     void getRenderedImage(std::vector<uint8_t>& image, const uint32_t resx, const uint32_t resy, float floatScaleFactor) {
-        const Pixel* p = reinterpret_cast<const Pixel*>(buffer.data());
-        image.resize((size_t)resx * resy * 4);
-        for (size_t i = 0; i < (size_t)resx * resy; i++) {
-            image[4 * i + 0] = x86FloatToU8(floatScaleFactor * p[i].r);
-            image[4 * i + 1] = x86FloatToU8(floatScaleFactor * p[i].g);
-            image[4 * i + 2] = x86FloatToU8(floatScaleFactor * p[i].b);
-            image[4 * i + 3] = 255u;
-        }
+        convertStorage(image, resx, resy, floatScaleFactor, false);   // the loop of :212-219, row stripes in parallel
     }
 
     virtual void saveRenderedImage(const char* png_filename = "pathtracer.png") override {
         std::vector<uint8_t> image;
         constexpr float scaleFactor = 1.0f;   // pathtracerApp.h:227
         printf("writing %s\n", png_filename);
+        auto t0 = std::chrono::steady_clock::now();
         if (gpuPostprocess) {
             image.swap(rgba8);   // converted and rotated on the device
         } else {
-            getRenderedImage(image, resx, resy, scaleFactor);
-            // due to the pinhole camera the image is upside-down and mirrored — undo that (pathtracerApp.h:235-243)
-            uint32_t* pRGBA = reinterpret_cast<uint32_t*>(image.data());
-            for (uint32_t y = 0; y < resy; y++) {
-                for (uint32_t x = 0; x < resx / 2; x++) {
-                    uint32_t from = x + y * resx;
-                    uint32_t to = (resx - 1) - x + ((resy - 1) - y) * resx;
-                    std::swap(pRGBA[from], pRGBA[to]);
-                }
-            }
+            // getRenderedImage, then: due to the pinhole camera the image is upside-down and mirrored — undo that (pathtracerApp.h:235-243:
+            // every pixel of the left half swapped with its point reflection).  One pass here: each converted pixel is written to the
+            // place the swap loop would leave it in (the same bytes, incl. an odd width's untouched middle column).
+            convertStorage(image, resx, resy, scaleFactor, true);
         }
+        auto t1 = std::chrono::steady_clock::now();
         std::string err = writePng(png_filename, image.data(), resx, resy);
         if (!err.empty()) printf("encoder error: %s", err.c_str());
+        times.convertMs = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        times.pngMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
     }
 
-    const std::vector<float>& storageBuffer() const { return buffer; }
+    const HostStorage& storageBuffer() const { return buffer; }
 
 private:
     struct Pixel { float r, g, b, a; };
