@@ -58,25 +58,37 @@ WORKLOAD_ALIAS = {"pathtrace": "K2", "mandelbrot": "K1", "mandelbrot_ds": "K1ds"
 PROFILE_TAG = {"K2": {"fast": "pt_fast", "strict": "pt_strict"}, "K1": "mandel", "K1ds": "mandel_ds"}
 
 
-PROFILE_ROUNDS = ("r04", "r03", "r02", "r01d", "r01c")
+PROFILE_ROUNDS = ("r05", "r04", "r03", "r02", "r01d", "r01c")
+_STALE = {}      # profile file -> why it is not quoted (build id of another library)
 
 
 def profiled_summary(cfg_name, args, n):
     """The committed rocprofv3 PMC summary (profiles/<round>_<tag>_pmc_summary.json) of this exact configuration, newest round
-    first; None when the run is not a profiled configuration (N > 1, overridden sizes)."""
+    first; None when the run is not a profiled configuration (N > 1, overridden sizes) — or when the summary was taken on ANOTHER
+    BUILD: tools/summarize_prof.py stamps each summary with mc_build_id() of the library it profiled (the source hash of the kernel
+    family), and a figure measured on other code is not this run's (`roofline.executed_source` then says so instead of quoting it)."""
     if n != 1 or args.width or args.height or args.spp or cfg_name not in PROFILE_TAG:
         return None, None
     tag = PROFILE_TAG[cfg_name]
     if isinstance(tag, dict):
         tag = tag[args.math]
+    family = "pt" if CONFIGS[cfg_name]["kind"] == "pt" else "mandel"
     for rnd in PROFILE_ROUNDS:
         path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}_pmc_summary.json")
         if os.path.exists(path):
             try:
-                entries = {k: v for k, v in json.load(open(path)).items() if "pathtrace" in k or "mandelbrot_kernel" in k}
-                return (entries, os.path.basename(path)) if entries else (None, None)
+                doc = json.load(open(path))
             except (ValueError, OSError):
                 return None, None
+            import __graft_entry__ as entry
+            mine = entry.load_package().bindings.build_id().get(family)
+            theirs = (doc.get("_build") or {}).get(family)
+            if theirs != mine:
+                _STALE[cfg_name] = (f"profiles/{os.path.basename(path)} was taken on build {family}={theirs or 'unstamped'}, the loaded library "
+                                    f"is {family}={mine}: not quoted")
+                return None, None
+            entries = {k: v for k, v in doc.items() if "pathtrace" in k or "mandelbrot_kernel" in k}
+            return (entries, os.path.basename(path)) if entries else (None, None)
     return None, None
 
 
@@ -138,6 +150,84 @@ def lavapipe_probe():
     return found
 
 
+APP_DIR = os.path.join(ROOT, "vulkan-compute-tests_amd", "bin")
+
+
+def app_command(cfg_name, route, out_png, math="fast"):
+    """The standalone app's command line for a BASELINE configuration (the reference's main.cpp surface + this repo's options)."""
+    cfg = CONFIGS[cfg_name]
+    if cfg["kind"] == "pt":
+        cmd = [os.path.join(APP_DIR, "pathtracer"), str(cfg["spp"]), str(cfg["H"]), "--math", math]
+        assert cfg["W"] == cfg["H"] * 3 // 2        # main.cpp:24: resx = resy * 3 / 2
+    else:
+        cmd = [os.path.join(APP_DIR, "mandelbrot"), "--width", str(cfg["W"]), "--height", str(cfg["H"]), "--max-iter", str(cfg["M"])]
+        if cfg["ds"]:
+            cmd += ["--precision", "ds", "--centre", repr(K4_VIEW["centre"][0]), repr(K4_VIEW["centre"][1]),
+                    "--scale", repr(K4_VIEW["scale"][0]), repr(K4_VIEW["scale"][1])]
+    cmd += ["--quiet", "--timing-json", "--out", out_png]
+    if route == "rgba8":
+        cmd += ["--gpu-postprocess"]
+    return cmd
+
+
+def end_to_end(cfg_names=("K2", "K4"), math="fast", probe=None):
+    """"end-to-end seconds incl. gather, D2H, convert, PNG (reported separately)" — the standalone apps (the reference's
+    main.cpp flow: init, preRun, run, saveRenderedImage) run as child processes with --timing-json, through both routes:
+      host_buffer: run() fills the application's pinned 16-B/pixel storage buffer (mc_*_render), saveRenderedImage converts on the host
+                   (float -> u8, + the path tracer's rotation; row stripes on all cores) and writes the PNG  — the reference's own flow;
+      rgba8:       --gpu-postprocess: conversion (+ rotation) on the device, 4 B/pixel cross PCIe (mc_*_render_rgba8).
+    Times are milliseconds of ONE cold process each (HIP start-up is `init`); d2h_gbps = bytes copied / the copy's device time, beside
+    `probe` = a pinned hipMemcpy of the same size (GB/s) when the caller measured one."""
+    import subprocess
+    import tempfile
+    out = {}
+    with tempfile.TemporaryDirectory(prefix="mc_e2e_") as tmp:
+        for name in cfg_names:
+            cfg = CONFIGS[name]
+            entry = {"image": [cfg["W"], cfg["H"]]}
+            for route in ("host_buffer", "rgba8"):
+                png = os.path.join(tmp, f"{name}_{route}.png")
+                p = subprocess.run(app_command(name, route, png, math), capture_output=True, text=True, timeout=600)
+                line = [ln for ln in p.stdout.splitlines() if ln.startswith('{"timing_ms"')]
+                if p.returncode != 0 or not line:
+                    entry[route] = {"error": (p.stdout + p.stderr)[-300:]}
+                    continue
+                t = json.loads(line[0])["timing_ms"]
+                nbytes = cfg["W"] * cfg["H"] * (16 if route == "host_buffer" else 4)
+                t["d2h_bytes"] = nbytes
+                t["d2h_gbps"] = nbytes / (t["copy"] * 1e-3) / 1e9 if t["copy"] > 0 else None
+                if probe and probe.get(nbytes):
+                    t["d2h_probe_gbps"] = probe[nbytes]
+                    t["d2h_vs_probe"] = t["d2h_gbps"] / probe[nbytes] if t["d2h_gbps"] else None
+                t["png_bytes"] = os.path.getsize(png) if os.path.exists(png) else None
+                entry[route] = t
+            out[name] = entry
+    out["note"] = ("one cold app process per entry (bin/pathtracer, bin/mandelbrot --timing-json); ms; init = HIP start-up + context, alloc = "
+                   "the pinned storage buffer (mc_host_alloc), run = the blocking render call = kernel + copy (device time) + launch / sync, "
+                   "convert = host float -> u8 (+ rotation; 0 when done on the device), png = encode + write, total = process wall time")
+    return out
+
+
+def pinned_copy_probe(sizes, torch):
+    """Device -> pinned host memory, GB/s per size (best of 5 after a warm-up): the rate the storage buffer's trip could reach."""
+    res = {}
+    for n in sizes:
+        src = torch.empty(n, dtype=torch.uint8, device="cuda")
+        dst = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+        best = 1e9
+        for rep in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dst.copy_(src, non_blocking=True)
+            e1.record()
+            torch.cuda.synchronize()
+            if rep:
+                best = min(best, e0.elapsed_time(e1))
+        res[n] = n / (best * 1e-3) / 1e9
+        del src, dst
+    return res
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,6 +240,7 @@ def parse():
                          "tests/test_gpu_fullsize.py pins it at K2), strict = IEEE + mc math (bit-identical to the oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the end_to_end block (the standalone apps timed as child processes)")
     ap.add_argument("--spp", type=int, default=None, help="override spp (diagnostics only; invalidates the headline)")
     ap.add_argument("--width", type=int, default=None, help="override image width (diagnostics only)")
     ap.add_argument("--height", type=int, default=None, help="override image height (per GPU for weak scaling; diagnostics only)")
@@ -410,12 +501,13 @@ def main():
         achieved_tflops = local_units * flops_per_unit / (kernel_ms * 1e-3) / 1e12
         if is_pt:   # the kernel the host selected for this request (mc_pathtrace_select_kernel: the same decision the launch made)
             ki = B.pathtrace_select_kernel(p)
-            fast_ran = ki.math_mode == B.PT_MATH_FAST
+            fast_ran = ki.math_mode != B.PT_MATH_STRICT
             pl, sp = B.default_scene()
             disjoint = (not fast_ran) or bool(B.pathtrace_scene_class(pl, sp) & B.PT_SCENE_SPHERES_DISJOINT)   # (template default: true)
-            kern = (f"pathtrace_pool_kernel<{'true' if fast_ran else 'false'}, {ki.lanes_per_pixel}, 3, {'true' if disjoint else 'false'}>"
+            # (the math tier is an int template parameter since round 5 — 0 strict, 1 fast, 2 careful — and rocprofv3 prints it so)
+            kern = (f"pathtrace_pool_kernel<{ki.math_mode}, {ki.lanes_per_pixel}, 3, {'true' if disjoint else 'false'}>"
                     if ki.kernel == B.PT_KERNEL_POOL
-                    else f"pathtrace_kernel<{B.PT_KERNEL_NAMES[ki.kernel]}, fast={str(fast_ran).lower()}, S={ki.lanes_per_pixel}>")
+                    else f"pathtrace_kernel<{B.PT_KERNEL_NAMES[ki.kernel]}, tier={ki.math_mode}, S={ki.lanes_per_pixel}>")
         else:
             kern = "mandelbrot_kernel<StateDS>" if cfg["ds"] else "mandelbrot_kernel<StateF32>"
         traffic, traffic_source = profiled_traffic(cfg_name, args, n)
@@ -424,16 +516,14 @@ def main():
         # also writes its 4-B iteration count, the parity object).  More launches per step or an accumulator re-read show up
         # in `traffic` (PMC) and in `traffic_ratio`, not here.
         alg_bytes = W * rows_local * (16 if is_pt else 20)
-        # The clock the kernel itself held, from the committed PMC pass of this configuration (GRBM_GUI_ACTIVE / 8 XCDs / duration).
-        # NOT mc_context_measure_clock: that probe reads the clock under ITS OWN dense FMA chain — 2.15 GHz after a K3 step during
-        # which the path tracer held 2.38 GHz (profiles/r04_k3_clock.txt) — and is kept only to compare boxes.
-        # (cycles of the profiled launch / the LIVE, unprofiled kernel time: a launch's cycle count is reproducible to < 1 %, while the
-        # profiled duration of a 14 ms kernel carries the counters' start / stop overhead)
-        prof_entries, _ = profiled_summary(cfg_name, args, n)
+        # The clock the kernel itself held: GRBM_GUI_ACTIVE / 8 XCDs / the duration of the SAME profiled launches (tools/summarize_prof.py,
+        # `kernel_clock_ghz`), quoted only from a summary of this build (profiled_summary).  NOT mc_context_measure_clock: that probe
+        # reads the clock under ITS OWN dense FMA chain — 2.15 GHz after a K3 step during which the path tracer held 2.38 GHz
+        # (profiles/r04_k3_clock.txt) — and is kept only to compare boxes.
+        prof_entries, prof_file = profiled_summary(cfg_name, args, n)
         prof_ghz = None
         if prof_entries and len(prof_entries) == 1:
-            cyc = next(iter(prof_entries.values())).get("derived", {}).get("gpu_cycles_per_xcd")
-            prof_ghz = cyc / (kernel_ms * 1e6) if cyc else None
+            prof_ghz = next(iter(prof_entries.values())).get("derived", {}).get("kernel_clock_ghz")
         contracted = is_pt and args.math == "fast"
         if is_pt and args.math == "fast":
             note = ("fast math: hardware transcendentals, a*b+c contraction, identities of exact arithmetic not executed (toleranced "
@@ -472,12 +562,16 @@ def main():
                        **({"verified_equal_to_single_gpu": verified} if verified is not None else {})},
             "roofline": {"bound": "valu", "kernel": kern, "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_TFLOPS,
-                         "kernel_clock_ghz": prof_ghz,   # GRBM_GUI_ACTIVE / 8 of the committed PMC pass / live kernel time
+                         "kernel_clock_ghz": prof_ghz,   # of the profiled launches themselves (same pass: cycles / duration)
+                         "kernel_clock_source": (f"profiles/{prof_file}: GRBM_GUI_ACTIVE / 8 / the profiled launches' own duration" if prof_ghz else None),
                          **({"frac_at_kernel_clock": achieved_tflops * 1e12 / (2.0 * cus * 4 * 32 * prof_ghz * 1e9)} if prof_ghz else {}),
+                         # `frac` is defined on the REFERENCE's arithmetic (algorithmic flops per unit); `executed_frac` is the hardware's
+                         # view — the fp32 lane-flops the ALUs performed (PMC instruction mix x active lanes) over the same time
                          # executed fp32 lane-flops (committed PMC instruction mix) over the live kernel time
                          "executed": (exec_flops / (kernel_ms * 1e-3) / 1e12) if exec_flops else None,
                          "executed_frac": (exec_flops / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS) if exec_flops else None,
-                         "executed_source": exec_source,
+                         "executed_source": exec_source or _STALE.get(cfg_name),
+                         "build_id": B.lib().mc_build_id().decode(),
                          "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_ratio": (traffic / alg_bytes) if traffic else None,
                          "kernel_ms": kernel_ms, "flops_per_unit": flops_per_unit,
@@ -509,10 +603,18 @@ def main():
         it64 = itr.to(torch.int64)
         pi = int(torch.where(it64 < k1["M"], it64 + 1, torch.full_like(it64, k1["M"])).sum().item())
         tf = pi * FLOPS_PER_PIXEL_ITER_F32 / (ms * 1e-3) / 1e12
+        k1_args = argparse.Namespace(width=None, height=None, spp=None, math=args.math)
+        k1_exec, k1_exec_src = profiled_executed_lane_flops("K1", k1_args, 1)
         out["secondary"] = {"metric": "Mandelbrot pixel-iters/s", "value": pi / (ms * 1e-3), "unit": "pixel-iters/s",
                             "workload": f"K1: mandelbrot {k1['W']}x{k1['H']} M{k1['M']} fp32", "pixel_iters": pi, "kernel_ms": ms,
+                            "unit_note": "reference-equivalent pixel-iterations (n + 1 per escaping pixel, M per interior pixel)",
                             "roofline": {"bound": "valu", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                                         "frac": tf / PEAK_FP32_TFLOPS, "lane_ops_frac": tf * 1e12 / PEAK_LANE_OPS}}
+                                         "frac": tf / PEAK_FP32_TFLOPS, "lane_ops_frac": tf * 1e12 / PEAK_LANE_OPS,
+                                         "frac_note": "reference-equivalent work per second over the peak: converged tiles leave early (exact cycle "
+                                                      "detection), so this is NOT a utilisation figure and may exceed 1 in lane-op terms; the hardware "
+                                                      "fraction is executed_frac",
+                                         "executed_frac": (k1_exec / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS) if k1_exec else None,
+                                         "executed_source": k1_exec_src or _STALE.get("K1")}}
         if args.math == "fast" and not (args.width or args.height or args.spp):
             # the same workload with MC_PT_MATH_STRICT (IEEE divide/sqrt + mc_math: bit-identical to the oracle)
             ps = B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_STRICT)
@@ -528,6 +630,12 @@ def main():
             sms = e0.elapsed_time(e1) / reps
             out["strict_math"] = {"metric": metric, "value": W * H * spp / (sms * 1e-3), "unit": unit, "kernel_ms": sms,
                                   "note": "bit-identical to the CPU oracle (tests/test_gpu_parity.py)"}
+
+    # ---- end to end: the standalone apps as child processes, K2 and K4, both routes; rank 0, N = 1, headline only ----
+    if (rank == 0 and n == 1 and cfg_name == "K2" and not args.no_end_to_end and not (args.width or args.height or args.spp)
+            and not profiler_preload()):      # (under a profiler's preload no child process is started: spawn_ranks)
+        sizes = sorted({CONFIGS[c]["W"] * CONFIGS[c]["H"] * b for c in ("K2", "K4") for b in (16, 4)})
+        out["end_to_end"] = end_to_end(("K2", "K4"), args.math, pinned_copy_probe(sizes, torch))
 
     # ---- CPU baseline: rank 0, N = 1, outside the timed region, a bounded sample of the same workload ----------------
     if rank == 0 and n == 1 and not args.no_cpu_baseline:

@@ -126,7 +126,14 @@ int mc_mandelbrot_colour_lut(uint32_t max_iter, const float k_color[4], float* l
  *      PathtracerApp::createCommandBuffer (src/pathtracerApp.h:358-378), fused into one launch ------ */
 enum {
     MC_PT_MATH_STRICT = 0, /* IEEE div/sqrt + the explicit "mc math" sin/cos/pow: bit-identical to the oracle */
-    MC_PT_MATH_FAST = 1    /* gfx950 hardware rcp/rsq/sqrt/sin/cos/exp/log: toleranced parity    */
+    MC_PT_MATH_FAST = 1,   /* toleranced parity (RMSE <= 0.5, 99.9-percentile per-pixel L2 <= 4 of 255 at 500 spp).  */
+                           /* The library renders the request with whatever holds that bound on the scene given: the fast tier      */
+                           /* (gfx950 hardware rcp/rsq/sqrt/sin/cos/exp/log, a*b+c contracted) up to four spheres; the careful tier  */
+                           /* below from five spheres on; the strict kernels for a light all but enclosed by an opaque sphere.       */
+                           /* mc_pathtrace_select_kernel reports which (mc_pathtrace_kernel_info.math_mode).                         */
+    MC_PT_MATH_FAST_CAREFUL = 2 /* the fast mode's careful tier on request: the same kernels and shortcuts, division / sqrt / 1/sqrt */
+                           /* rounded as the reference rounds them and no contraction — a sample differs from the reference's by far  */
+                           /* fewer roundings and takes another path correspondingly less often; 1.2 - 1.3 x the fast tier's time     */
 };
 
 /* mc_pathtrace_params.flags: MC_PT_PRECISION(x) below (bits 16-19) is the one field a binding sets.  Bits 0-15 belong to this
@@ -201,11 +208,15 @@ int mc_pathtrace_render_rgba8(mc_context* ctx, const mc_pathtrace_params* p, con
  * mirror sphere.  Next-event estimation at point-blank range through rays grazing the sphere they start on (pathTracer.comp:325-327,
  * 420) makes such an image a collection of near-ties, which fast math decides differently from the reference arithmetic far more
  * often than its tolerance allows: an MC_PT_MATH_FAST request for such a scene is RENDERED WITH THE STRICT KERNELS
- * (bit-identical to the oracle), never silently outside the bound. */
+ * (bit-identical to the oracle), never silently outside the bound.  Bit 4 (MC_PT_SCENE_MANY_SPHERES) — any scene: five or more spheres.
+ * The share of fast-math samples that take another path than the reference's grows with the number of (specular) spheres a path can
+ * run through; the fast tier holds the bound with margin up to four and crosses it at six (profiles/r05_fork_census_careful.txt): an
+ * MC_PT_MATH_FAST request for such a scene is rendered by the careful tier (MC_PT_MATH_FAST_CAREFUL). */
 #define MC_PT_SCENE_SLAB 1u
 #define MC_PT_SCENE_LIGHTS_INSIDE 2u
 #define MC_PT_SCENE_SPHERES_DISJOINT 4u   /* slab scenes: the spheres are pairwise disjoint (the fast pool kernel then needs no square roots for shadow rays) */
 #define MC_PT_SCENE_LIGHT_ENCLOSED 8u     /* a light intersecting a diffuse sphere / all but enclosed by a mirror: fast math requests are rendered strict */
+#define MC_PT_SCENE_MANY_SPHERES 16u      /* any scene with five or more spheres: an MC_PT_MATH_FAST request is rendered by the careful tier            */
 int mc_pathtrace_scene_class(const float* planes, uint32_t n_planes, const float* spheres, uint32_t n_spheres,
                              uint32_t* out_class);
 
@@ -223,7 +234,8 @@ enum {
 typedef struct mc_pathtrace_kernel_info {
     uint32_t kernel;          /* MC_PT_KERNEL_*                                                                             */
     uint32_t lanes_per_pixel; /* sample-parallel width S: lanes of a wave that share a pixel (1, 4 or 16)                    */
-    uint32_t math_mode;       /* the mode that RUNS: MC_PT_MATH_STRICT for a fast request on an MC_PT_SCENE_LIGHT_ENCLOSED scene */
+    uint32_t math_mode;       /* the mode that RUNS: for a fast request MC_PT_MATH_FAST, MC_PT_MATH_FAST_CAREFUL (MC_PT_SCENE_MANY_SPHERES) */
+                              /* or MC_PT_MATH_STRICT (MC_PT_SCENE_LIGHT_ENCLOSED)                                              */
     uint32_t launches;        /* kernel launches per call (2: a ragged sample count in the round-synchronous kernels)        */
 } mc_pathtrace_kernel_info;
 int mc_pathtrace_select_kernel(const mc_pathtrace_params* p, const float* planes, uint32_t n_planes, const float* spheres,

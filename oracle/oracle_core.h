@@ -164,6 +164,7 @@ struct PlainPolicy {
     static inline void c_intersect() {}
     static inline void c_bounce() {}
     static inline void c_material(int) {}   // hook: the material branch a surviving bounce takes (tools/sched_sim.cpp)
+    static inline void c_hit(int) {}        // hook: the kind of object a bounce hit, 0 plane / 1 sphere (tools/sched_sim.cpp)
     static inline void c_sample() {}
 };
 struct CountPolicy {
@@ -181,6 +182,7 @@ struct CountPolicy {
     static inline void c_intersect() { tls_counts()->intersect_calls++; }
     static inline void c_bounce() { tls_counts()->bounces++; }
     static inline void c_material(int) {}
+    static inline void c_hit(int) {}
     static inline void c_sample() { tls_counts()->samples++; }
 };
 
@@ -632,6 +634,7 @@ struct PT {
             HitInfo hit;
             if (!intersect(ray, hit)) continue;                            // :369
             P::c_bounce();
+            P::c_hit(hit.objType);
             v3 x = add(ray.o, muls(ray.d, hit.rayT));                      // :374  o + t*d
             const float* obj = (hit.objType == ePlane) ? planes + 12 * hit.objIdx : spheres + 12 * hit.objIdx;
             int mat = (int)std::floor(P::add(obj[11], 0.5f));              // :378/:384

@@ -124,3 +124,70 @@ def test_apps_pixels_through_the_reference_codec_give_the_reference_bytes(B, O, 
                        text=True, cwd=tmp_path)   # (the round-3 flag is still accepted)
     assert r.returncode == 0
     assert np.array_equal(np.asarray(Image.open(tmp_path / "fast.png").convert("RGBA")), exp)
+
+
+def test_apps_at_default_sizes_decode_to_the_reference_pixels(B, O, tmp_path):
+    """The shipped path's pixel contract at the reference's own defaults: `mandelbrot` (2000 x 2000, M = 128, main.cpp:20)
+    and `pathtracer` (500 spp, 900 x 600, main.cpp:22-24; strict math, the default) write PNGs that decode to exactly the RGBA8 pixels
+    the reference's host post-process makes of the oracle's storage buffer — through the pinned storage buffer and the stripe-parallel
+    host conversion (round 5).  An odd width (51 x 34) runs the rotation's middle-column quirk through the same parallel loop, and
+    --fast-png says what it no longer does."""
+    from PIL import Image
+    Image.MAX_IMAGE_PIXELS = None
+    bindir = os.path.join(os.path.dirname(os.path.dirname(B.LIB_PATH)), "bin")
+    r = subprocess.run([os.path.join(bindir, "mandelbrot"), "--timing-json"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    _, lut_u8 = O.mandel_lut(128)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "mandelbrot.png").convert("RGBA")), lut_u8[O.mandelbrot_iters(2000, 2000, 128)])
+    import json
+    t = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"timing_ms"')][0])["timing_ms"]
+    assert t["kernel"] > 0 and t["copy"] > 0 and t["convert"] > 0 and t["png"] > 0 and t["total"] >= t["run"] + t["convert"] + t["png"]
+    r = subprocess.run([os.path.join(bindir, "pathtracer"), "--quiet"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref = O.pathtrace(900, 600, 500, math_mode=O.MATH_MC)
+    exp = O.rotate180(O.float_to_rgba8(ref, 1.0).reshape(600, 900, 4), 900, 600)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "pathtracer.png").convert("RGBA")), exp)
+    for threads in ("1", "3", "0"):
+        r = subprocess.run([os.path.join(bindir, "pathtracer"), "3", "34", "--quiet", "--png-threads", threads, "--out", "odd.png", "--fast-png"],
+                           capture_output=True, text=True, cwd=tmp_path)
+        assert r.returncode == 0 and "--fast-png has no effect" in r.stdout
+        ref = O.pathtrace(51, 34, 3, math_mode=O.MATH_MC)
+        assert np.array_equal(np.asarray(Image.open(tmp_path / "odd.png").convert("RGBA")), O.rotate180(O.float_to_rgba8(ref, 1.0).reshape(34, 51, 4), 51, 34))
+
+
+def test_pinned_and_pageable_callers_get_identical_bytes_at_the_pinned_rate(ctx, B):
+    """the application owns a page-locked storage buffer (mc_host_alloc: what stands where the reference allocates its
+    buffer HOST_VISIBLE | HOST_COHERENT, vulkanComputeApp.cpp:489-533).  A pageable caller gets the same bytes; the copy into the pinned
+    buffer runs at >= 80 % of what a plain pinned hipMemcpy of the same size reaches (K1's 122.9 MB vec4 buffer; device time of the
+    copy from mc_context_last_timing)."""
+    import torch
+    W, H = 3200, 2400
+    p = B.mandelbrot_params(W, H, max_iter=100)
+    with B.HostBuffer((H, W, 4)) as hb:
+        best = 1e9
+        for _ in range(4):
+            hb.array[...] = 0
+            ctx.mandelbrot(p, want_iters=False, out=hb.array)
+            kernel_ms, copy_ms = ctx.last_timing()
+            assert kernel_ms > 0 and copy_ms > 0
+            best = min(best, copy_ms)
+        pageable, _ = ctx.mandelbrot(p, want_iters=False)
+        assert np.array_equal(pageable.view(np.uint32), hb.array.view(np.uint32))
+        q = B.pathtrace_params(96, 64, 8)
+        small = ctx.pathtrace(q)
+        with B.HostBuffer((64, 96, 4)) as hs:
+            assert np.array_equal(ctx.pathtrace(q, out=hs.array).view(np.uint32), small.view(np.uint32))
+        nbytes = W * H * 16
+        src = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        dst = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+        probe = 1e9
+        for rep in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); dst.copy_(src, non_blocking=True); e1.record(); torch.cuda.synchronize()
+            if rep:
+                probe = min(probe, e0.elapsed_time(e1))
+        print(f"D2H of {nbytes / 1e6:.1f} MB into mc_host_alloc memory: {nbytes / best / 1e6:.1f} GB/s; pinned torch copy: {nbytes / probe / 1e6:.1f} GB/s")
+        assert probe / best >= 0.8, (best, probe)
+    with B.Context(0) as fresh:      # before the first blocking host-buffer call there is nothing to report
+        with pytest.raises(B.McError):
+            fresh.last_timing()

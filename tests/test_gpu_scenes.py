@@ -240,14 +240,15 @@ def box_scene(O, n_spheres, rng, lights=1):
 def test_box_with_one_to_eight_spheres_runs_the_specialised_kernels(ctx, B, O, n_spheres, lights):
     """SURVEY §8(f)4 for the fast path: the axis-aligned box with 1 .. 8 spheres takes the slab / closed-box /
     sample-pool kernels (instantiated per sphere count) instead of the generic one.  Strict: the pool kernel, the round-synchronous
-    slab kernel at every width and the generic kernel all equal the oracle bit for bit.  Fast: RMSE <= 0.5 on every scene; the
-    99.9-percentile bound of 4 — stated for the reference scene at 500 spp — holds up to five spheres; with eight (five to seven
-    specular surfaces instead of two) more samples fork and the percentile reaches 5.5: asserted <= 8 there, with the share of
-    pixels further than 4 from the oracle below 0.4 % (each of them a forked sample, not a drift: the mean stays put)."""
+    slab kernel at every width and the generic kernel all equal the oracle bit for bit.  Fast: the stated bound — RMSE <= 0.5 and
+    99.9-percentile L2 <= 4 at 500 spp, never edited — on EVERY scene (round 4 asserted 8 from six spheres on, where
+    the fast tier measures 4.4 - 5.6).  From five spheres on the host renders an MC_PT_MATH_FAST request with the careful tier
+    (MC_PT_MATH_FAST_CAREFUL: the same kernels without contraction, division / sqrt / rsq rounded as the reference rounds them —
+    fewer differently rounded operations, fewer forked samples: 1.3 - 3.0 on these scenes), reported by mc_pathtrace_select_kernel."""
     rng = np.random.default_rng(40 + 10 * n_spheres + lights)
     planes, spheres = box_scene(O, n_spheres, rng, lights)
     cls = B.pathtrace_scene_class(planes, spheres)
-    assert cls == B.PT_SCENE_SLAB | B.PT_SCENE_LIGHTS_INSIDE | B.PT_SCENE_SPHERES_DISJOINT, cls
+    assert cls == B.PT_SCENE_SLAB | B.PT_SCENE_LIGHTS_INSIDE | B.PT_SCENE_SPHERES_DISJOINT | (B.PT_SCENE_MANY_SPHERES if n_spheres >= 5 else 0), cls
     W, H, spp = 40, 24, 37
     ref = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC)
     p = B.pathtrace_params(W, H, spp)
@@ -266,10 +267,12 @@ def test_box_with_one_to_eight_spheres_runs_the_specialised_kernels(ctx, B, O, n
     libm = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_LIBM)[..., :3].astype(np.float64)
     for flags in (0, B.PT_NO_POOL_KERNEL):
         q = B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, flags=flags)
-        assert B.pathtrace_select_kernel(q, planes, spheres).kernel == (B.PT_KERNEL_BOX if flags else B.PT_KERNEL_POOL)
+        ki = B.pathtrace_select_kernel(q, planes, spheres)
+        assert ki.kernel == (B.PT_KERNEL_BOX if flags else B.PT_KERNEL_POOL)
+        assert ki.math_mode == (B.PT_MATH_FAST_CAREFUL if n_spheres >= 5 else B.PT_MATH_FAST)
         d = ctx.pathtrace(q, planes=planes, spheres=spheres)[..., :3].astype(np.float64) - libm
         rmse, p999 = float(np.sqrt((d ** 2).mean())), float(np.percentile(np.sqrt((d ** 2).sum(-1)), 99.9))
         print(f"{n_spheres} spheres / {lights} lights, flags {flags}: fast vs oracle(libm) rmse {rmse:.4f}  p99.9 L2 {p999:.3f}  mean {d.mean():+.5f}")
         far = float((np.sqrt((d ** 2).sum(-1)) > 4.0).mean())
         assert np.isfinite(d).all() and rmse <= 0.5 and abs(d.mean()) < 0.03 and far <= 0.004, (flags, rmse, p999, far)
-        assert p999 <= (4.0 if n_spheres <= 5 else 8.0), (flags, rmse, p999)
+        assert p999 <= 4.0, (flags, rmse, p999)

@@ -39,19 +39,20 @@ out = {{}}
 with B.Context(0) as ctx:
     for k in range(int(z["n"])):
         planes, spheres = z[f"planes{{k}}"], z[f"spheres{{k}}"]
-        flags = int(os.environ.get("MC_PT_FLAGS", "0"), 0)
-        q = B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, flags=flags)
+        flags, MODE = {flags}, {mode}
+        q = B.pathtrace_params(W, H, spp, math_mode=MODE, flags=flags)
         out[f"tm{{k}}"] = ctx.pathtrace(q, planes=planes, spheres=spheres)
-        q = B.pathtrace_params(W, H, spp + 1, math_mode=B.PT_MATH_FAST, flags=flags, sample_begin=0, sample_end=spp)
+        q = B.pathtrace_params(W, H, spp + 1, math_mode=MODE, flags=flags, sample_begin=0, sample_end=spp)
         out[f"lin{{k}}"] = ctx.pathtrace(q, planes=planes, spheres=spheres)
-        out[f"kernel{{k}}"] = np.int32(B.pathtrace_select_kernel(q, planes, spheres).kernel)
+        ki = B.pathtrace_select_kernel(q, planes, spheres)
+        out[f"kernel{{k}}"] = np.int32(ki.kernel + 10 * ki.math_mode)
     if {time}:   # kernel time at 900 x 600, 100 spp (device form, HIP events on the launch stream)
         import torch
         st = torch.cuda.Stream(); torch.cuda.set_stream(st); s = st.cuda_stream
         buf = torch.zeros((600, 900, 4), dtype=torch.float32, device="cuda")
         for k in range(int(z["n"])):
             planes, spheres = z[f"planes{{k}}"], z[f"spheres{{k}}"]
-            q = B.pathtrace_params(900, 600, 100, math_mode=B.PT_MATH_FAST, flags=int(os.environ.get("MC_PT_FLAGS", "0"), 0))
+            q = B.pathtrace_params(900, 600, 100, math_mode={mode}, flags={flags})
             for _ in range(2): ctx.pathtrace_device(q, buf.data_ptr(), planes=planes, spheres=spheres, stream=s)
             torch.cuda.synchronize()
             best = 1e9
@@ -92,6 +93,8 @@ def main():
                     help="ref = the reference scene; n:l = tests' box scene with n spheres, l lights (the test's seed); n:l:seed = another "
                          "seed; n:l:seed:spec = every sphere that is not a light made specular (mirror / glass alternating)")
     ap.add_argument("--time", action="store_true", help="also time each scene at 900 x 600, 100 spp")
+    ap.add_argument("--modes", default="fast", help="comma list of: fast (the request as a caller makes it: the host may render it with the careful "
+                    "tier or strict), tier1 (the fast tier itself, MC_PT_NO_FAST_GUARD), careful (MC_PT_MATH_FAST_CAREFUL), strict")
     ap.add_argument("--size", type=int, nargs=2, default=[300, 200])
     ap.add_argument("--spp", type=int, default=500)
     a = ap.parse_args()
@@ -102,6 +105,10 @@ def main():
     for tok in a.scenes.split(","):
         if tok == "ref":
             scenes.append((O.DEFAULT_PLANES.copy().reshape(6, 12), O.DEFAULT_SPHERES.copy().reshape(3, 12)))
+        elif tok.startswith("g:"):    # g:planes:spheres:lights[:seed] — the tests' random GENERIC scene (any planes, spheres anywhere)
+            from test_gpu_scenes import random_scene
+            f = [int(x) for x in tok.split(":")[1:]]
+            scenes.append(random_scene(np.random.default_rng(f[3] if len(f) > 3 else 100 + f[1]), f[0], f[1], f[2]))
         else:
             f = tok.split(":")
             n, l = int(f[0]), int(f[1])
@@ -129,18 +136,20 @@ def main():
         mats = [int(x) for x in scenes[k][1][:, 11]]
         print(f"scene {nm}: sphere materials {mats}, emitters {[int(bool(s[4:7].any())) for s in scenes[k][1]]}")
         print(fmt("oracle mc math (yardstick)", stats(refs[k][2], refs[k][0]), lin_rel(refs[k][3], refs[k][1])), flush=True)
-    for lib in a.libs:
-        out = os.path.join(tmp, os.path.basename(lib) + ".npz")
-        r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT, scenes=sfile, W=W, H=H, spp=a.spp, out=out, time=bool(a.time))],
+    MODES = {"fast": (1, 0), "tier1": (1, 64), "careful": (2, 0), "strict": (0, 0)}
+    for lib, mode in [(l, m) for l in a.libs for m in a.modes.split(",")]:
+        out = os.path.join(tmp, os.path.basename(lib) + "." + mode + ".npz")
+        r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT, scenes=sfile, W=W, H=H, spp=a.spp, out=out, time=bool(a.time),
+                                                               mode=MODES[mode][0], flags=MODES[mode][1])],
                            env=dict(os.environ, MC_LIB_PATH=os.path.abspath(lib)), capture_output=True, text=True)
         if r.returncode != 0:
             print(f"{os.path.basename(lib)}: FAILED {r.stderr[-400:]}", flush=True)
             continue
         z = np.load(out)
-        print(f"{os.path.basename(lib)}", flush=True)
+        print(f"{os.path.basename(lib)}, request: {mode}", flush=True)
         for k, nm in enumerate(names):
             ms = f"  {float(z[f'ms{k}']):.3f} ms / 100 spp at 900 x 600" if a.time else ""
-            print(fmt(f"scene {nm} (kernel {int(z[f'kernel{k}'])})", stats(z[f"tm{k}"], refs[k][0]), lin_rel(z[f"lin{k}"], refs[k][1])) + ms, flush=True)
+            print(fmt(f"scene {nm} ({['strict', 'fast', 'careful'][int(z[f'kernel{k}']) // 10]} {int(z[f'kernel{k}']) % 10})", stats(z[f"tm{k}"], refs[k][0]), lin_rel(z[f"lin{k}"], refs[k][1])) + ms, flush=True)
 
 
 if __name__ == "__main__":

@@ -19,9 +19,11 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 import __graft_entry__ as entry  # noqa: E402
 
 
-def scene(rng, O, enclose=False):
+def scene(rng, O, enclose=False, many=False):
     planes = O.DEFAULT_PLANES.copy().reshape(6, 12)
-    ns = int(rng.choice([3, 3, 3, 1, 2, 4, 5, 6, 8]))          # 1 .. 8 spheres take the specialised kernels (round 4)
+    # 1 .. 8 spheres take the specialised kernels (round 4); --many weights 5 .. 8 up: the counts an MC_PT_MATH_FAST request is rendered
+    # by the careful tier for (round 5)
+    ns = int(rng.choice([6, 7, 8, 8, 5, 6, 7, 3, 4] if many else [3, 3, 3, 1, 2, 4, 5, 6, 8]))
     spheres = np.zeros((ns, 12), np.float32)
     planes[:, 3] *= rng.uniform(0.85, 1.25, 6).astype(np.float32)
     planes[:, 8:11] = rng.uniform(0.05, 0.999, (6, 3)).astype(np.float32)
@@ -65,23 +67,30 @@ def main():
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--enclose", action="store_true", help="aim a third of the scenes at the enclosed-light boundary (scene class bit 3)")
+    ap.add_argument("--many", action="store_true", help="weight scenes with 5 .. 8 spheres up (rendered by the careful tier)")
     args = ap.parse_args()
     B, O = entry.load_package().bindings, entry.load_oracle()
     ctx = B.Context(0)
     rng = np.random.default_rng(args.seed)
-    n = {"cases": 0, "closed_box": 0, "disjoint": 0, "guarded": 0}
+    n = {"cases": 0, "closed_box": 0, "disjoint": 0, "guarded": 0, "careful": 0}
     worst = {"frac_far": 0.0, "mean": 0.0}
     bad = []
     t0 = last = time.time()
     while time.time() - t0 < args.seconds:
-        planes, spheres = scene(rng, O, args.enclose)
+        planes, spheres = scene(rng, O, args.enclose, args.many)
         cls = B.pathtrace_scene_class(planes, spheres)
         W, H = int(rng.integers(8, 40)), int(rng.integers(8, 28))
         spp = int(rng.choice([16, 24, 33, 64, 100]))
         depth = int(rng.choice([12, 12, 5, 8]))
         flags = int(rng.choice([0, 0, 0, B.PT_NO_POOL_KERNEL, B.pt_force_s(16), B.pt_force_s(1)]))
-        out = ctx.pathtrace(B.pathtrace_params(W, H, spp, max_depth=depth, math_mode=B.PT_MATH_FAST, flags=flags), planes=planes, spheres=spheres)
+        q = B.pathtrace_params(W, H, spp, max_depth=depth, math_mode=B.PT_MATH_FAST, flags=flags)
+        out = ctx.pathtrace(q, planes=planes, spheres=spheres)
         n["cases"] += 1
+        ran = B.pathtrace_select_kernel(q, planes, spheres).math_mode      # the tier that rendered the request
+        n["careful"] += int(ran == B.PT_MATH_FAST_CAREFUL)
+        if (ran == B.PT_MATH_STRICT) != bool(cls & B.PT_SCENE_LIGHT_ENCLOSED) or \
+           (ran == B.PT_MATH_FAST_CAREFUL) != (len(spheres) >= 5 and not cls & B.PT_SCENE_LIGHT_ENCLOSED):
+            bad.append(f"tier {ran} does not follow the scene class {cls} with {len(spheres)} spheres")
         if cls & B.PT_SCENE_LIGHT_ENCLOSED:   # classified outside the fast tolerance: the strict kernels must have rendered it
             n["guarded"] += 1
             mc = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC, max_depth=depth)

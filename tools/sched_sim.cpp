@@ -29,8 +29,9 @@ namespace {
 
 thread_local std::vector<uint8_t>* g_events = nullptr;
 struct TracePolicy : oracle::PlainPolicy {
-    static inline void c_bounce() { g_events->push_back(0); }             // a hit; stays 0 if RR terminates it
-    static inline void c_material(int m) { g_events->back() = (uint8_t)m; }
+    static inline void c_bounce() { g_events->push_back(0); }             // a hit; the material bits stay 0 if RR terminates it
+    static inline void c_hit(int type) { g_events->back() |= (uint8_t)(type ? 4 : 0); }   // bit 2: the object is a sphere
+    static inline void c_material(int m) { g_events->back() |= (uint8_t)m; }
 };
 
 const float kPlanes[6 * 12] = {
@@ -48,7 +49,7 @@ const float kSpheres[3 * 12] = {
 // its last material.)
 int path_iterations(const std::vector<uint8_t>& ev) {
     int n = 0;
-    for (uint8_t e : ev) n += e != 0;
+    for (uint8_t e : ev) n += (e & 3) != 0;
     return n;
 }
 
@@ -135,15 +136,231 @@ void sim_pool(const Seq& seq, int spp, bool continuous, Stats& st) {
     }
 }
 
+
+// ---- a STRUCTURAL scheme, priced before it is built ------------------------------------------------------------
+// The pool kernel's iteration costs ~375 instruction-equivalents, ~60 of which — sphere normal, mirror / glass — serve the 8 of 64
+// lanes that sit on a sphere, in 98 % of the iterations (profiles/r03_pool_region_stats.txt).  "split": a lane whose path's NEXT hit is
+// a sphere PARKS that path (16 dwords through LDS, one slot per lane) and takes its pixel's next sample; iterations then bounce off
+// walls only.  When `threshold` lanes hold a parked (or stalled: slot occupied) sphere path, ONE sphere phase runs those bounces at
+// full width: the parked path changes places with the lane's active one, which waits in the slot as "ready" and is taken back before
+// any new sample.  No path state moves between lanes; a wave's schedule still depends on nothing outside the wave.
+// Both schedulers are priced with the SAME per-block costs (static VALU instructions x runs, transcendentals at 5: the table in
+// profiles/r03_pool_region_stats.txt), a block being paid whenever ANY lane of the wave needs it — as the hardware does.
+struct Costs {
+    double control = 16, take = 12, batch = 174, prologue = 40, normal = 14, specular = 45, diffuse = 92, wall_bounce = 32,
+           general_bounce = 32, intersect = 45, roots = 28, rand = 20, roulette = 10;
+    double park = 14, unpark = 14, swap = 30;   // split only: LDS traffic + address / flag bookkeeping, per block execution (--park / --swap)
+};
+struct Path { const std::vector<uint8_t>* ev; size_t pos; };   // pos: index of the next EXECUTED bounce (events with material bits)
+static bool path_done(const Path& p) { return !p.ev || p.pos >= p.ev->size() || ((*p.ev)[p.pos] & 3) == 0; }
+static bool wants_sphere(const Path& p) { return !path_done(p) && ((*p.ev)[p.pos] & 4); }
+
+struct SplitStats { double cost = 0, iters = 0, phases = 0, lane_work = 0, stalled = 0; long samples = 0; };
+
+// events[pixel][sample]; split = false prices the pool kernel as built (one block schedule, every block paid when any lane needs it)
+void sim_cost(const std::vector<std::vector<std::vector<uint8_t>>>& tile, int spp, bool split, int threshold, const Costs& c, SplitStats& st) {
+    const int S = 16;
+    const long n_batches = (spp + S - 1) / S;
+    long batch = 0, ghead[4] = {0, 0, 0, 0};
+    Path act[64], slot[64];
+    int slot_state[64];   // 0 empty, 1 parked (wants a sphere phase), 2 ready
+    for (int l = 0; l < 64; l++) { act[l] = Path{nullptr, 0}; slot[l] = Path{nullptr, 0}; slot_state[l] = 0; }
+    auto free_lane = [&](int l) { return path_done(act[l]); };
+    for (long guard = 0; guard < 100000000; guard++) {
+        double cost = c.control;
+        // ---- refill: a ready path first, else the pixel's next stash entry
+        bool any_unpark = false, any_take = false;
+        if (split)
+            for (int l = 0; l < 64; l++)
+                if (free_lane(l) && slot_state[l] == 2) { act[l] = slot[l]; slot_state[l] = 0; any_unpark = true; }
+        int need[4] = {0, 0, 0, 0};
+        bool any_dead = false;
+        for (int l = 0; l < 64; l++) if (free_lane(l)) { need[l / S]++; any_dead = true; }
+        if (any_dead) {
+            bool some_wants = false, some_full = false;
+            for (int p = 0; p < 4; p++) {
+                const long avail = batch * S - ghead[p];
+                some_wants |= need[p] > avail;
+                some_full |= avail > S;
+            }
+            if (batch < n_batches && some_wants && !some_full) { batch++; cost += c.batch; }
+            for (int p = 0; p < 4; p++) {
+                const long avail = batch * S - ghead[p];
+                long rank = 0;
+                for (int j = 0; j < S; j++) {
+                    const int l = p * S + j;
+                    if (!free_lane(l)) continue;
+                    if (rank < avail) {
+                        const long e = ghead[p] + rank;
+                        if (e < spp) { act[l] = Path{&tile[p][(size_t)e], 0}; st.samples++; any_take = true; }
+                    }
+                    rank++;
+                }
+                ghead[p] += std::min<long>(need[p], avail);
+            }
+            cost += c.take * (any_take ? 1 : 0);
+        }
+        if (any_unpark) cost += c.unpark;
+        // ---- anything left?
+        int alive = 0, parked = 0;
+        for (int l = 0; l < 64; l++) { alive += !free_lane(l); parked += slot_state[l] != 0; }
+        bool drained = batch >= n_batches;
+        for (int p = 0; p < 4; p++) drained &= ghead[p] == batch * S;
+        if (!alive && !parked && drained) break;
+        auto bounce_blocks = [&](bool sphere_phase, int& served) {   // prices one bounce of the lanes that take part; advances them
+            bool any_sphere = false, any_spec = false, any_diffuse = false, any_wall = false, any_gen = false, any_rr = false;
+            served = 0;
+            for (int l = 0; l < 64; l++) {
+                if (free_lane(l)) continue;
+                const bool sph = wants_sphere(act[l]);
+                if (split && sph != sphere_phase) continue;      // not this kind of iteration: the lane idles (stalled)
+                const uint8_t e = (*act[l].ev)[act[l].pos];
+                const int mat = e & 3;
+                any_sphere |= sph; any_spec |= mat != 1; any_diffuse |= mat == 1; any_wall |= mat == 1 && !sph; any_gen |= mat == 1 && sph;
+                any_rr |= act[l].pos >= 5;
+                act[l].pos++;
+                served++;
+            }
+            double k = c.prologue + c.intersect + c.roots + c.rand;
+            if (any_sphere) k += c.normal;
+            if (any_spec) k += c.specular;
+            if (any_diffuse) k += c.diffuse;
+            if (any_wall) k += c.wall_bounce;
+            if (any_gen) k += c.general_bounce;
+            if (any_rr) k += c.roulette;
+            return k;
+        };
+        int served = 0;
+        if (!split) {
+            if (alive) { cost += bounce_blocks(false, served); st.iters++; st.lane_work += served; }
+        } else {
+            int want = 0, wall = 0;
+            for (int l = 0; l < 64; l++) {
+                if (slot_state[l] == 1) want++;
+                if (!free_lane(l)) { if (wants_sphere(act[l])) want++; else wall++; }
+            }
+            const bool phase = want > 0 && (want >= threshold || wall == 0);
+            if (phase) {
+                // a parked path changes places with the lane's active one (which waits as "ready"); a stalled one is in place already
+                for (int l = 0; l < 64; l++)
+                    if (slot_state[l] == 1) {
+                        if (!free_lane(l) && wants_sphere(act[l])) continue;   // both want the phase: the active one first, the slot stays
+                        const Path a = act[l];
+                        act[l] = slot[l];
+                        if (!path_done(a)) { slot[l] = a; slot_state[l] = 2; } else slot_state[l] = 0;
+                    }
+                cost += c.swap + bounce_blocks(true, served);
+                st.phases++; st.lane_work += served;
+            } else if (wall) {
+                cost += bounce_blocks(false, served);
+                st.iters++; st.lane_work += served;
+            }
+            // a path whose next hit is a sphere parks as soon as its lane's slot is free (end of the iteration: the hit is known)
+            bool any_park = false;
+            for (int l = 0; l < 64; l++)
+                if (!free_lane(l) && wants_sphere(act[l])) {
+                    if (slot_state[l] == 0) { slot[l] = act[l]; slot_state[l] = 1; act[l] = Path{nullptr, 0}; any_park = true; }
+                    else st.stalled++;
+                }
+            if (any_park) cost += c.park;
+        }
+        st.cost += cost;
+    }
+}
+
+
+// "two paths per lane" (the form VERDICT r4 item 6 names): a lane holds TWO paths in registers and advances, in every iteration, one
+// that fits the iteration's kind — a wall iteration (no sphere blocks) or, when `threshold` lanes hold a path whose next hit is a
+// sphere, a sphere iteration.  A lane idles only when neither of its paths fits.  `select` = what choosing the working path costs an
+// iteration (the state of both paths lives in registers: a select per state register read, or a masked swap).
+void sim_two_paths(const std::vector<std::vector<std::vector<uint8_t>>>& tile, int spp, int threshold, const Costs& c, double select, SplitStats& st,
+                   bool mixed = false) {   // mixed: in a sphere iteration the other lanes bounce off walls (every block paid, as today)
+    const int S = 16;
+    const long n_batches = (spp + S - 1) / S;
+    long batch = 0, ghead[4] = {0, 0, 0, 0};
+    Path pa[64][2];
+    for (auto& q : pa) q[0] = q[1] = Path{nullptr, 0};
+    for (long guard = 0; guard < 100000000; guard++) {
+        double cost = c.control + select;
+        int need[4] = {0, 0, 0, 0};
+        bool any_dead = false;
+        for (int l = 0; l < 64; l++) for (int k = 0; k < 2; k++) if (path_done(pa[l][k])) { need[l / S]++; any_dead = true; }
+        if (any_dead) {
+            bool some_wants = false, some_full = false, any_take = false;
+            for (int p = 0; p < 4; p++) {
+                const long avail = batch * S - ghead[p];
+                some_wants |= need[p] > avail;
+                some_full |= avail > S;
+            }
+            if (batch < n_batches && some_wants && !some_full) { batch++; cost += c.batch; }
+            for (int p = 0; p < 4; p++) {
+                const long avail = batch * S - ghead[p];
+                long rank = 0;
+                for (int j = 0; j < S; j++)
+                    for (int k = 0; k < 2; k++) {
+                        const int l = p * S + j;
+                        if (!path_done(pa[l][k])) continue;
+                        if (rank < avail) {
+                            const long e = ghead[p] + rank;
+                            if (e < spp) { pa[l][k] = Path{&tile[p][(size_t)e], 0}; st.samples++; any_take = true; }
+                        }
+                        rank++;
+                    }
+                ghead[p] += std::min<long>(need[p], avail);
+            }
+            if (any_take) cost += c.take;
+        }
+        int alive = 0, want = 0, wall = 0;
+        for (int l = 0; l < 64; l++) {
+            bool w = false, s = false;
+            for (int k = 0; k < 2; k++) if (!path_done(pa[l][k])) { alive++; (wants_sphere(pa[l][k]) ? s : w) = true; }
+            want += s; wall += w;
+        }
+        bool drained = batch >= n_batches;
+        for (int p = 0; p < 4; p++) drained &= ghead[p] == batch * S;
+        if (!alive && drained) break;
+        const bool phase = want > 0 && (want >= threshold || wall == 0);
+        bool any_spec = false, any_diffuse = false, any_wall = false, any_gen = false, any_rr = false;
+        int served = 0;
+        for (int l = 0; l < 64; l++) {
+            int pick = -1;
+            for (int k = 0; k < 2; k++) if (!path_done(pa[l][k]) && wants_sphere(pa[l][k]) == phase) { pick = k; break; }
+            if (pick < 0 && mixed && phase)
+                for (int k = 0; k < 2; k++) if (!path_done(pa[l][k])) { pick = k; break; }
+            if (pick < 0) { if (!path_done(pa[l][0]) || !path_done(pa[l][1])) st.stalled++; continue; }
+            Path& q = pa[l][pick];
+            const int mat = (*q.ev)[q.pos] & 3;
+            const bool sph = wants_sphere(q);
+            any_spec |= mat != 1; any_diffuse |= mat == 1; any_wall |= mat == 1 && !sph; any_gen |= mat == 1 && sph; any_rr |= q.pos >= 5;
+            q.pos++;
+            served++;
+        }
+        double k = c.prologue + c.intersect + c.roots + c.rand;
+        if (phase) k += c.normal;
+        if (any_spec) k += c.specular;
+        if (any_diffuse) k += c.diffuse;
+        if (any_wall) k += c.wall_bounce;
+        if (any_gen) k += c.general_bounce;
+        if (any_rr) k += c.roulette;
+        cost += k;
+        (phase ? st.phases : st.iters)++;
+        st.lane_work += served;
+        st.cost += cost;
+    }
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
     int W = 900, H = 600, spp = 500, max_depth = 12, n_seqs = 48, Lmax = 8;
     unsigned seed = 1;
+    Costs costs;
     for (int i = 1; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--spp")) spp = atoi(argv[i + 1]);
         if (!strcmp(argv[i], "--seqs")) n_seqs = atoi(argv[i + 1]);
         if (!strcmp(argv[i], "--seed")) seed = atoi(argv[i + 1]);
+        if (!strcmp(argv[i], "--park")) costs.park = costs.unpark = atof(argv[i + 1]);
+        if (!strcmp(argv[i], "--swap")) costs.swap = atof(argv[i + 1]);
     }
     oracle::PT<TracePolicy> pt;
     pt.planes = kPlanes; pt.nPlanes = 6; pt.spheres = kSpheres; pt.nSpheres = 3; pt.mathMode = oracle::MATH_LIBM;
@@ -197,6 +414,48 @@ int main(int argc, char** argv) {
         snprintf(name, sizeof name, "continuous, %d tiles per wave", L);
         c.print(name, ideal);
         printf("%-46s -> %.2f %% fewer iterations than one tile per wave\n", "", 100.0 * (1.0 - c.iters / p1.iters));
+    }
+    // ---- the split scheme (sphere bounces batched into phases) against the pool kernel as built, both priced per block
+    {
+        SplitStats base;
+        for (auto& sq : ev) for (auto& tile : sq) sim_cost(tile, spp, false, 0, costs, base);
+        printf("\ncost model, instruction-equivalents per sample (park / unpark %.0f, swap %.0f per block execution):\n", costs.park, costs.swap);
+        printf("  %-44s %8.2f per sample, %6.1f per iteration, %5.2f lanes served (%ld samples)\n", "pool kernel as built",
+               base.cost / base.samples, base.cost / base.iters, base.lane_work / base.iters, base.samples);
+        for (int T : {8, 16, 24, 32, 48}) {
+            SplitStats sp;
+            for (auto& sq : ev) for (auto& tile : sq) sim_cost(tile, spp, true, T, costs, sp);
+            printf("  split, sphere phase at %2d waiting lanes       %8.2f per sample (%+6.2f %%): %.1f wall iterations + %.1f phases per 64 samples, "
+                   "%.2f lanes per bounce block, %.2f stalled lanes per block\n", T, sp.cost / sp.samples,
+                   100.0 * (sp.cost / sp.samples / (base.cost / base.samples) - 1.0), sp.iters * 64.0 / sp.samples, sp.phases * 64.0 / sp.samples,
+                   sp.lane_work / (sp.iters + sp.phases), sp.stalled / (sp.iters + sp.phases));
+        }
+    }
+    {
+        SplitStats base;
+        for (auto& sq : ev) for (auto& tile : sq) sim_cost(tile, spp, false, 0, costs, base);
+        for (double select : {0.0, 20.0})
+            for (int T : {8, 16, 24, 32, 48}) {
+                SplitStats sp;
+                for (auto& sq : ev) for (auto& tile : sq) sim_two_paths(tile, spp, T, costs, select, sp);
+                printf("  two paths per lane, select %2.0f, sphere iteration at %2d lanes %8.2f per sample (%+6.2f %%): %.1f wall + %.1f sphere iterations per 64 "
+                       "samples, %.2f lanes per block, %.2f idle lanes\n", select, T, sp.cost / sp.samples,
+                       100.0 * (sp.cost / sp.samples / (base.cost / base.samples) - 1.0), sp.iters * 64.0 / sp.samples, sp.phases * 64.0 / sp.samples,
+                       sp.lane_work / (sp.iters + sp.phases), sp.stalled / (sp.iters + sp.phases));
+            }
+    }
+    {
+        SplitStats base;
+        for (auto& sq : ev) for (auto& tile : sq) sim_cost(tile, spp, false, 0, costs, base);
+        for (double select : {0.0, 20.0})
+            for (int T : {4, 8, 16, 24, 32}) {
+                SplitStats sp;
+                for (auto& sq : ev) for (auto& tile : sq) sim_two_paths(tile, spp, T, costs, select, sp, true);
+                printf("  two paths per lane, MIXED sphere iterations, select %2.0f, at %2d lanes %8.2f per sample (%+6.2f %%): %.1f wall-only + %.1f mixed iterations "
+                       "per 64 samples, %.2f lanes per block, %.2f idle lanes\n", select, T, sp.cost / sp.samples,
+                       100.0 * (sp.cost / sp.samples / (base.cost / base.samples) - 1.0), sp.iters * 64.0 / sp.samples, sp.phases * 64.0 / sp.samples,
+                       sp.lane_work / (sp.iters + sp.phases), sp.stalled / (sp.iters + sp.phases));
+            }
     }
     return 0;
 }

@@ -5,8 +5,12 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def short(name):
@@ -68,6 +72,11 @@ def main():
             # got > 1: in a real mix the classes overlap.  The floor these kernels reach is ~2.45 cycles per instruction.
             d["simd_cycles_per_valu_inst"] = (c["GRBM_GUI_ACTIVE"] / 8.0) / (c["SQ_INSTS_VALU"] / 1024.0)
         e["derived"] = d
+    # Which build these counters were taken on: mc_build_id() of the library the profiled bench.py loaded (run this script in the same
+    # gpurun call as the profile).  bench.py quotes a summary only when the id of its kernel family equals the loaded library's.
+    import __graft_entry__ as entry
+    B = entry.load_package().bindings
+    summary["_build"] = dict(B.build_id(), library=os.path.relpath(B.LIB_PATH, ROOT))
     json.dump(summary, open(out + "_pmc_summary.json", "w"), indent=1)
     print(json.dumps(summary, indent=1))
 

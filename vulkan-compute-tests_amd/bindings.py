@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mc_compute.h")
 
 MC_OK = 0
 PRECISION_F32, PRECISION_DS = 0, 1
-PT_MATH_STRICT, PT_MATH_FAST = 0, 1
+PT_MATH_STRICT, PT_MATH_FAST, PT_MATH_FAST_CAREFUL = 0, 1, 2
 MANDEL_FMA = 1
 MANDEL_ITERS_U16 = 2   # device form: d_iters is a uint16 plane (max_iter <= 65535): the multi-GPU exchange format
 PT_GENERIC_KERNEL = 1
@@ -212,7 +212,7 @@ def tile_rows(p):
     return int(lib().mc_tile_rows(p.row_begin, p.row_end, p.row_block, p.row_stride))
 
 
-PT_SCENE_SLAB, PT_SCENE_LIGHTS_INSIDE, PT_SCENE_SPHERES_DISJOINT, PT_SCENE_LIGHT_ENCLOSED = 1, 2, 4, 8
+PT_SCENE_SLAB, PT_SCENE_LIGHTS_INSIDE, PT_SCENE_SPHERES_DISJOINT, PT_SCENE_LIGHT_ENCLOSED, PT_SCENE_MANY_SPHERES = 1, 2, 4, 8, 16
 PT_KERNEL_GENERIC, PT_KERNEL_SLAB, PT_KERNEL_BOX, PT_KERNEL_POOL, PT_KERNEL_GENERIC_MEMORY = 0, 1, 3, 4, 5
 PT_KERNEL_NAMES = {0: "generic", 1: "slab", 3: "box", 4: "pool", 5: "generic_memory"}
 

@@ -7,8 +7,14 @@
 //        inversesqrt(x) := 1.0f / sqrt(x)
 //        sin/cos        := Cody–Waite pi/2 reduction + cephes sinf/cosf kernels (fmaf form)
 //        pow(x, y)      := exp2(y * log2(x)) with cephes-style logf/exp2f kernels (fmaf form)
-//  fast (Fast = true): gfx950 hardware approximations — v_rcp_f32, v_rsq_f32, v_sqrt_f32,
+//  fast (Fast = 1): gfx950 hardware approximations — v_rcp_f32, v_rsq_f32, v_sqrt_f32,
 //     v_sin_f32/v_cos_f32 (input in revolutions), v_exp_f32/v_log_f32.  ~1 ulp each; toleranced parity.
+//  careful (Fast = 2; the fast mode's second tier, include/mc_compute.h MC_PT_MATH_FAST_CAREFUL): division, square root and reciprocal
+//     square root ROUNDED AS THE REFERENCE ROUNDS THEM — the strict mode's short forms (one hardware seed + 3 .. 7 ordinary
+//     instructions) without their window tests; hardware sine / cosine / exp / log as in the fast tier.  Every fast-math shortcut
+//     that is an identity of exact arithmetic stays; the translation unit that instantiates it does not contract.  A path then differs
+//     from the reference's by far fewer roundings, and forks correspondingly less often (profiles/r05_fork_census*.txt).
+//  `Fast` is an int so that `if (Fast)` keeps meaning "not strict".
 //
 // Requires -ffp-contract=off (explicit __builtin_fmaf calls are the only fused operations).
 #pragma once
@@ -93,11 +99,10 @@ __device__ __forceinline__ float div_step(float a, float s, float y) {
 #ifndef MC_PT_FAST_ACCURATE_SINCOS
 #define MC_PT_FAST_ACCURATE_SINCOS 0
 #endif
-// MC_PT_FAST_SHORT: the fast mode's division, square root and reciprocal square root ROUNDED AS THE REFERENCE ROUNDS THEM — the short
-// forms of the strict mode (one hardware seed + 3 .. 7 ordinary instructions; correct rounding enumerated over every fp32 pattern of
-// their windows, see sqrt_short / rcp_short / div_step / rsqrt_short below), without the strict mode's window tests: outside the windows
-// (denormal, infinite, NaN arguments — no finite path produces one) the result is merely inaccurate, and the one argument a path does
-// produce there, an exact zero under a square root, is selected per lane.
+// The careful tier (Fast == 2; MC_PT_FAST_SHORT = 1 gives the fast tier the same forms, for the census): the short forms of the strict
+// mode (correct rounding enumerated over every fp32 pattern of their windows, see sqrt_short / rcp_short / div_step / rsqrt_short below)
+// without the strict mode's window tests: outside the windows (denormal, infinite, NaN arguments — no finite path produces one) the
+// result is merely inaccurate, and the one argument a path does produce there, an exact zero under a square root, is selected per lane.
 #ifndef MC_PT_FAST_SHORT
 #define MC_PT_FAST_SHORT 0
 #endif
@@ -124,17 +129,17 @@ __device__ __forceinline__ float nt_sin_rev(float u) {      // sin(2 pi u), u in
     return y * (0.775f + 0.225f * __builtin_fabsf(y));
 }
 #endif
-template <bool Fast> __device__ __forceinline__ float fdiv(float a, float b) {
+template <int Fast> __device__ __forceinline__ float fdiv(float a, float b) {
 #ifdef MC_EXPERIMENT_NO_TRANS
     if (Fast) return a * nt_rcp(b);
 #endif
-    if (Fast && MC_PT_FAST_SHORT) return div_step(a, b, rcp_short(b));
+    if (Fast == 2 || (Fast && MC_PT_FAST_SHORT)) return div_step(a, b, rcp_short(b));
     if (Fast && !MC_PT_FAST_IEEE) return a * __builtin_amdgcn_rcpf(b);
     return ieee_div(a, b);
 }
 // (a0, a1, a2) / s.  Strict: the short division inside its window (wave-wide test), the compiler's IEEE expansion outside.
 // HaveY: the caller supplies y = RN(1/s) — a constant or a host-computed kernel argument — instead of rcp_short(s).
-template <bool Fast, bool HaveY> __device__ __forceinline__ void div3(float& a0, float& a1, float& a2, float s, float y) {
+template <int Fast, bool HaveY> __device__ __forceinline__ void div3(float& a0, float& a1, float& a2, float s, float y) {
     if constexpr (!Fast) {
         // the short form for every lane; the lanes outside the window (never seen in a render) redo it the long way
         const uint32_t b0 = as_uint(a0), b1 = as_uint(a1), b2 = as_uint(a2);
@@ -150,11 +155,11 @@ template <bool Fast, bool HaveY> __device__ __forceinline__ void div3(float& a0,
     }
     a0 = fdiv<Fast>(a0, s); a1 = fdiv<Fast>(a1, s); a2 = fdiv<Fast>(a2, s);
 }
-template <bool Fast> __device__ __forceinline__ float fsqrt(float a) {
+template <int Fast> __device__ __forceinline__ float fsqrt(float a) {
 #ifdef MC_EXPERIMENT_NO_TRANS
     if (Fast) return a * nt_rsq(a);
 #endif
-    if (Fast && MC_PT_FAST_SHORT) { const float r = sqrt_short(a); return a == 0.0f ? 0.0f : r; }
+    if (Fast == 2 || (Fast && MC_PT_FAST_SHORT)) { const float r = sqrt_short(a); return a == 0.0f ? 0.0f : r; }
     if (Fast && !MC_PT_FAST_IEEE) return __builtin_amdgcn_sqrtf(a);
     if (Fast) return ieee_sqrt(a);
 #ifdef MC_EXPERIMENT_NO_WINDOW_GUARD   // measurement only: what the per-call window tests cost (NOT exact outside the window)
@@ -163,11 +168,11 @@ template <bool Fast> __device__ __forceinline__ float fsqrt(float a) {
     if (__builtin_expect(wave_all(in_short_window(a)), 1)) return sqrt_short(a);
     return ieee_sqrt(a);
 }
-template <bool Fast> __device__ __forceinline__ float inversesqrt(float a) {
+template <int Fast> __device__ __forceinline__ float inversesqrt(float a) {
 #ifdef MC_EXPERIMENT_NO_TRANS
     if (Fast) return nt_rsq(a);
 #endif
-    if (Fast && MC_PT_FAST_SHORT) return rsqrt_short(a);
+    if (Fast == 2 || (Fast && MC_PT_FAST_SHORT)) return rsqrt_short(a);
     if (Fast && !MC_PT_FAST_IEEE) return __builtin_amdgcn_rsqf(a);
     if (Fast) return ieee_div(1.0f, ieee_sqrt(a));
 #ifdef MC_EXPERIMENT_NO_WINDOW_GUARD
@@ -227,7 +232,7 @@ __device__ __forceinline__ void mc_sincos(float x, float& s, float& c) {
 
 // sin/cos of angle = two_pi_f32 * u where `angle` is the already-rounded fp32 product the shader
 // computes (pathTracer.comp:412,426) and `u` the random number it came from.
-template <bool Fast> __device__ __forceinline__ void sincos_angle(float angle, float u, float& s, float& c) {
+template <int Fast> __device__ __forceinline__ void sincos_angle(float angle, float u, float& s, float& c) {
 #ifdef MC_EXPERIMENT_NO_TRANS
     if (Fast) { s = nt_sin_rev(u); c = nt_sin_rev(u + 0.25f); return; }
 #endif
@@ -282,7 +287,7 @@ __device__ __forceinline__ float mc_exp2(float y) {
     int e = (int)n + 127;
     return p * as_float((uint32_t)e << 23);
 }
-template <bool Fast> __device__ __forceinline__ float fpow(float x, float y) {
+template <int Fast> __device__ __forceinline__ float fpow(float x, float y) {
     if (Fast) return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));   // v_exp_f32(y * v_log_f32(x))
     return mc_exp2(y * mc_log2(x));
 }

@@ -214,6 +214,8 @@ static int multi_pathtrace(mc_multi* m, const mc_pathtrace_params* p, const floa
     if (!m || !p || (!out_rgba_f32 && !out_rgba8)) return MC_ERR_INVALID_ARGUMENT;
     if (p->row_begin != 0 || p->row_end != p->height || p->row_stride) return MC_ERR_INVALID_ARGUMENT;
     if (p->sample_begin != 0) return MC_ERR_UNSUPPORTED;   // progressive continuation: single-GPU entry points
+    // the RGBA8 form converts a FINISHED render (:453 applied): refused before anything is launched on any device
+    if (out_rgba8 && p->sample_end != p->spp) return MC_ERR_INVALID_ARGUMENT;
     const uint32_t W = p->width, H = p->height;
     const uint32_t padded = padded_tile_rows(H, m->n);
     int rc;
@@ -233,7 +235,6 @@ static int multi_pathtrace(mc_multi* m, const mc_pathtrace_params* p, const floa
     if (out_rgba_f32)
         MC_HIP_TRY(hipMemcpyAsync(out_rgba_f32, m->full_rgba.ptr, (size_t)W * H * 16, hipMemcpyDeviceToHost, c0->stream));
     if (out_rgba8) {   // pathtracerApp.h:202-243 on device 0
-        if (p->sample_end != p->spp) return MC_ERR_INVALID_ARGUMENT;
         if ((rc = m->full_u8.reserve((size_t)W * H * 4))) return rc;
         if ((rc = convert_rgba8_launch(c0, m->full_rgba.ptr, W, H, 1.0f, 1, m->full_u8.ptr, c0->stream))) return rc;
         MC_HIP_TRY(hipMemcpyAsync(out_rgba8, m->full_u8.ptr, (size_t)W * H * 4, hipMemcpyDeviceToHost, c0->stream));

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "pathtrace_kernel.h"
 
@@ -134,10 +135,19 @@ static bool spheres_disjoint(const float* spheres, uint32_t n_spheres) {
 //     the bound for every position but the light's last sliver);
 //   * j of glass: never (next-event estimation does not pass glass, :420; the light is seen through refraction only), two lights: never.
 constexpr double kLightGapMargin = 1.5, kMirrorMargin = 0.25;
-bool light_nearly_enclosed(const float* spheres, uint32_t n_spheres) {
+// Spheres from which an MC_PT_MATH_FAST request is rendered by the careful tier.  Measured on the test suite's boxes (300 x 200 x 500,
+// profiles/r05_fork_census_careful.txt; bound 4): the fast tier's 99.9-percentile reads 1.5 / 1.9 with four spheres, 3.2 with five,
+// 4.4 - 4.5 with six and seven, 5.2 - 5.6 with eight; the careful tier 1.3 with five, at most 3.0 with eight.
+constexpr uint32_t kCarefulSpheres = 5;
+static bool light_nearly_enclosed_scan(const float* spheres, uint32_t n_spheres) {
+    // the emissive spheres first (one pass; almost every scene has a handful), then each of them against the others
+    std::vector<uint32_t> lights;
     for (uint32_t i = 0; i < n_spheres; i++) {
         const float* si = spheres + 12 * i;
-        if (!(h_dot(v3{si[4], si[5], si[6]}, v3{si[4], si[5], si[6]}) > 0.0f)) continue;   // :407
+        if (h_dot(v3{si[4], si[5], si[6]}, v3{si[4], si[5], si[6]}) > 0.0f) lights.push_back(i);   // :407
+    }
+    for (uint32_t i : lights) {
+        const float* si = spheres + 12 * i;
         for (uint32_t j = 0; j < n_spheres; j++) {
             const float* sj = spheres + 12 * j;
             if (j == i || h_dot(v3{sj[4], sj[5], sj[6]}, v3{sj[4], sj[5], sj[6]}) > 0.0f) continue;
@@ -152,6 +162,27 @@ bool light_nearly_enclosed(const float* spheres, uint32_t n_spheres) {
     }
     return false;
 }
+// The scan is O(lights x spheres) and runs for every fast-math launch, scene-class and kernel query (generic scenes are accepted up to
+// 2^20 objects): the answer for the LAST table seen by this thread is kept, keyed by the table's length and a 64-bit hash of its bytes
+// (one multiply-xor per 8 bytes: ~1 ms per 10^5 spheres), so a render loop over one scene pays the scan once.
+bool light_nearly_enclosed(const float* spheres, uint32_t n_spheres) {
+    if (n_spheres < 2u) return false;
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ n_spheres;
+    const size_t words = (size_t)n_spheres * 6u;                 // 12 floats = 6 x 8 bytes per record
+    for (size_t k = 0; k < words; k++) {
+        uint64_t w;
+        std::memcpy(&w, reinterpret_cast<const char*>(spheres) + 8 * k, 8);
+        h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+        h ^= h >> 32;
+    }
+    thread_local uint64_t cached_hash = 0;
+    thread_local uint32_t cached_n = 0;
+    thread_local bool cached_result = false;
+    if (cached_n == n_spheres && cached_hash == h) return cached_result;
+    cached_result = light_nearly_enclosed_scan(spheres, n_spheres);
+    cached_n = n_spheres; cached_hash = h;
+    return cached_result;
+}
 
 // Host-side scene analysis behind mc_pathtrace_scene_class (no device involved): bit 0 = the scene takes the slab
 // kernels, bit 1 = its shadow rays skip the plane tests, bit 2 = its three spheres are pairwise disjoint, bit 3 = a light is
@@ -160,7 +191,8 @@ uint32_t pathtrace_scene_class(const float* planes, uint32_t n_planes, const flo
     PTArgs a;
     std::memset(&a, 0, sizeof(a));
     set_camera(a);
-    const uint32_t ill = light_nearly_enclosed(spheres, n_spheres) ? MC_PT_SCENE_LIGHT_ENCLOSED : 0u;
+    const uint32_t ill = (light_nearly_enclosed(spheres, n_spheres) ? MC_PT_SCENE_LIGHT_ENCLOSED : 0u) |
+                         (n_spheres >= kCarefulSpheres ? MC_PT_SCENE_MANY_SPHERES : 0u);
     if (!analyse_slabs(planes, n_planes, n_spheres, a.scene)) return ill;
     return 1u | (lights_inside_box(a.scene, spheres, n_spheres, a.cam_o, a.lc) ? 2u : 0u) | (spheres_disjoint(spheres, n_spheres) ? 4u : 0u) | ill;
 }
@@ -186,7 +218,7 @@ int pathtrace_plan(const mc_pathtrace_params* p, const float* planes, uint32_t n
     if (!p->width || !p->height || !p->spp || p->row_end > p->height || p->row_begin >= p->row_end ||
         p->sample_end > p->spp || p->sample_begin >= p->sample_end)   // an empty range would re-apply the epilogue (:453)
         return MC_ERR_INVALID_ARGUMENT;
-    if (p->math_mode != MC_PT_MATH_STRICT && p->math_mode != MC_PT_MATH_FAST) return MC_ERR_INVALID_ARGUMENT;
+    if (p->math_mode != MC_PT_MATH_STRICT && p->math_mode != MC_PT_MATH_FAST && p->math_mode != MC_PT_MATH_FAST_CAREFUL) return MC_ERR_INVALID_ARGUMENT;
     if (p->row_stride && (!p->row_block || p->row_block > p->row_stride)) return MC_ERR_INVALID_ARGUMENT;
     // flags: bits 0, 2-6 diagnostics, bits 8-15 MC_PT_FORCE_S, bits 16-19 MC_PT_PRECISION; everything else is reserved (bit 1 was the
     // removed lane-regrouping experiment) and refused, so that a stray bit never selects a kernel silently
@@ -210,11 +242,15 @@ int pathtrace_plan(const mc_pathtrace_params* p, const float* planes, uint32_t n
         set_error_detail("more than 2^20 objects");
         return MC_ERR_UNSUPPORTED;
     }
-    // Fast math never runs where it cannot hold its tolerance (light_nearly_enclosed): such a request is rendered strict.
+    // Fast math never runs where it cannot hold its tolerance: a scene with a light all but enclosed by an opaque sphere
+    // (light_nearly_enclosed) is rendered strict; a scene with kCarefulSpheres or more spheres by the careful tier (pathtrace_careful.hip:
+    // the share of samples that fork grows with the sphere count, and the fast tier's 99.9-percentile crosses the bound at six).
     plan.math_mode = p->math_mode;
-    if (p->math_mode == MC_PT_MATH_FAST && !(p->flags & MC_PT_NO_FAST_GUARD) && light_nearly_enclosed(spheres, n_spheres))
-        plan.math_mode = MC_PT_MATH_STRICT;
-    const bool fast = plan.math_mode == MC_PT_MATH_FAST;
+    if (p->math_mode != MC_PT_MATH_STRICT && !(p->flags & MC_PT_NO_FAST_GUARD)) {
+        if (light_nearly_enclosed(spheres, n_spheres)) plan.math_mode = MC_PT_MATH_STRICT;
+        else if (n_spheres >= kCarefulSpheres) plan.math_mode = MC_PT_MATH_FAST_CAREFUL;
+    }
+    const bool fast = plan.math_mode != MC_PT_MATH_STRICT;
     std::memset(&a, 0, sizeof(a));
     a.W = p->width; a.H = p->height; a.spp = p->spp;
     a.sample_begin = p->sample_begin; a.sample_end = p->sample_end;
@@ -387,8 +423,9 @@ int pathtrace_launch(mc_context* ctx, const mc_pathtrace_params* p, const float*
         a.status = (uint32_t*)ctx->status.ptr;
     }
     auto launch = [&](const PTArgs& args, int width) {
-        return plan.math_mode == MC_PT_MATH_FAST ? pt::launch_fast(args, plan.variant, width, plan.prec, rows, s)
-                                                 : pt::launch_strict(args, plan.variant, width, plan.prec, rows, s);
+        return plan.math_mode == MC_PT_MATH_FAST           ? pt::launch_fast(args, plan.variant, width, plan.prec, rows, s)
+               : plan.math_mode == MC_PT_MATH_FAST_CAREFUL ? pt::launch_careful(args, plan.variant, width, plan.prec, rows, s)
+                                                           : pt::launch_strict(args, plan.variant, width, plan.prec, rows, s);
     };
     if (plan.tail_S) {
         const uint32_t rest = (p->sample_end - p->sample_begin) % (uint32_t)plan.S;

@@ -1,0 +1,24 @@
+// Instantiates the CAREFUL tier of the MC_PT_MATH_FAST path tracer kernels (Fast = 2, csrc/mc_math.h): every kernel family of
+// pathtrace_fast.hip with the same fast-math identities, but compiled WITHOUT contraction (this translation unit is built under the
+// command line's -ffp-contract=off, like the strict one) and with division, square root and reciprocal square root rounded as the
+// reference rounds them (the strict mode's short forms, unguarded).
+//
+// Why a second tier: a fast-math sample differs from the reference's by a rounding in almost every operation, and wherever a path
+// runs through specular spheres such a difference is amplified bounce by bounce until a discrete decision (which object, shadowed or
+// lit) goes the other way — the sample "forks" to another valid path.  The share of forked samples grows with the number of spheres:
+// the fast tier keeps the stated tolerance (RMSE 0.5 / 99.9-percentile L2 4 at 500 spp) with margin up to four spheres, reaches the
+// bound at five and exceeds it from six on (p99.9 4.4 .. 5.6).  The census (tools/fork_census.py, profiles/r05_fork_census*.txt) shows
+// what carries the forks: contraction and the hardware seeds' last bit, in equal parts — not any one shortcut.  With both removed the
+// same scenes read 1.9 .. 3.0 at 1.18 .. 1.30 of the fast tier's time (the strict kernels: 2.4 x).  The host selects this tier for an
+// MC_PT_MATH_FAST request on a scene with five or more spheres (csrc/pathtrace.hip), and for an explicit MC_PT_MATH_FAST_CAREFUL one.
+#include "pathtrace_kernel.h"
+#include "pathtrace_pool.h"
+
+namespace mc {
+namespace pt {
+int launch_careful(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s) {
+    if (variant == 4) return launch_pool<2>(a, S, tile_rows, s);
+    return launch_impl<2>(a, variant, S, prec, tile_rows, s);
+}
+}  // namespace pt
+}  // namespace mc

@@ -121,25 +121,25 @@ __device__ __forceinline__ float dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y
 __device__ __forceinline__ v3 cross(v3 a, v3 b) {
     return v3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
 }
-template <bool Fast> __device__ __forceinline__ v3 normalize(v3 a) { return a * dm::inversesqrt<Fast>(dot(a, a)); }
+template <int Fast> __device__ __forceinline__ v3 normalize(v3 a) { return a * dm::inversesqrt<Fast>(dot(a, a)); }
 // a / s, three numerators over one divisor.  Strict: the short division of mc_math.h inside its window (wave-wide test),
 // the compiler's IEEE expansion outside.  divs_recip: the caller supplies y = RN(1/s) (a constant, a host-computed argument).
-template <bool Fast, bool HaveY> __device__ __forceinline__ v3 divs_impl(v3 a, float s, float y) {
+template <int Fast, bool HaveY> __device__ __forceinline__ v3 divs_impl(v3 a, float s, float y) {
     dm::div3<Fast, HaveY>(a.x, a.y, a.z, s, y);
     return a;
 }
-template <bool Fast> __device__ __forceinline__ v3 divs(v3 a, float s) { return divs_impl<Fast, false>(a, s, 0.0f); }
-template <bool Fast> __device__ __forceinline__ v3 divs_recip(v3 a, float s, float y) { return divs_impl<Fast, true>(a, s, y); }
+template <int Fast> __device__ __forceinline__ v3 divs(v3 a, float s) { return divs_impl<Fast, false>(a, s, 0.0f); }
+template <int Fast> __device__ __forceinline__ v3 divs_recip(v3 a, float s, float y) { return divs_impl<Fast, true>(a, s, y); }
 // First tangent of the orthonormal basis around w (:409, :427): normalize(cross(|w.x| > 0.1 ? (0,1,0) : (1,0,0), w)).
 // Strict: the literal expression (its products with the axis' zeros decide the sign of zero components).
 // Fast (toleranced): the cross product is (w.z, 0, -w.x) or (0, -w.z, w.y) — one select, one fused squared length, two
 // scalings and three selects instead of two selects, nine cross-product operations, a 3-term dot and three scalings;
 // the non-zero components are the values the literal form produces under contraction.
-template <bool Fast> __device__ __forceinline__ v3 tangent_u(v3 w) {
+template <int Fast> __device__ __forceinline__ v3 tangent_u(v3 w) {
     const bool sel = __builtin_fabsf(w.x) > 0.1f;
     if constexpr (Fast) {
         const float q = sel ? w.x : w.y;
-        const float inv = dm::inversesqrt<true>(__builtin_fmaf(q, q, w.z * w.z));
+        const float inv = dm::inversesqrt<Fast>(__builtin_fmaf(q, q, w.z * w.z));
         const float zi = w.z * inv, qi = q * inv;
         return v3{sel ? zi : 0.0f, sel ? 0.0f : -zi, sel ? -qi : qi};
     } else {
@@ -149,9 +149,9 @@ template <bool Fast> __device__ __forceinline__ v3 tangent_u(v3 w) {
 // normalize() of a combination a*u + b*v + c*w of an orthonormal basis with a^2 + b^2 + c^2 = 1 (the sampled directions of
 // :413 and :428).  Strict: the literal normalize.  Fast (toleranced): the vector is already of unit length to within the
 // accuracy of v_sin/v_cos/v_sqrt (~1e-6), which is what the rescaling would remove; it is used as it is.
-template <bool Fast, bool UnitBasis> __device__ __forceinline__ v3 normalize_unit_combination(v3 a) {
-    if constexpr (Fast && UnitBasis && !MC_PT_FAST_RENORMALISE) return a;
-    else return normalize<Fast>(a);
+template <int Fast, bool UnitBasis> __device__ __forceinline__ v3 normalize_unit_combination(v3 a) {
+    if constexpr (Fast == 1 && UnitBasis && !MC_PT_FAST_RENORMALISE) return a;
+    else return normalize<Fast>(a);   // (the careful tier re-normalises as the reference does: profiles/r05_fork_bias_identities.txt)
 }
 // reflect(I,N) = I - 2*dot(N,I)*N
 __device__ __forceinline__ v3 reflect(v3 I, v3 N) { return I - N * (2.0f * dot(N, I)); }
@@ -236,7 +236,7 @@ __device__ __forceinline__ bool needs_precision(const float* sp, v3 o) {     // 
     return sp[3] > maxLen || dot(c, c) > maxLen * maxLen || dot(o, o) > maxLen * maxLen || dot(co, co) > maxLen * maxLen;
 }
 // Returns false for the shader's `continue` (det < 0); otherwise dd = the value the shader assigns to `d`.
-template <bool Fast, int Prec>
+template <int Fast, int Prec>
 __device__ __forceinline__ bool sphere_extended(const float* sp, float r2, v3 o, v3 d, float& dd) {
     auto rsq = [](float x) { return dm::inversesqrt<Fast>(x); };
     if (Prec == 1) {
@@ -328,7 +328,7 @@ template <int NS> struct HotSlabN {
 // gathers nothing: every later comparison with its NaN t is false) — so they and the final "anything hit?" select are dropped.
 // HaveOc: the caller passes c_i - o and its squared length (a COMPILE-TIME fact: a run-time "pointer given?" test on a private
 // array is not foldable on this target — address 0 is a valid stack address — and kept the 8-sphere array in scratch memory).
-template <bool Fast, bool Closed, bool OccR2, int StatsBase, bool HaveOc, int NS>   // OccR2: occ[i] holds |c_i - o|^2 - r_i^2 (fast math)
+template <int Fast, bool Closed, bool OccR2, int StatsBase, bool HaveOc, int NS>   // OccR2: occ[i] holds |c_i - o|^2 - r_i^2 (fast math)
 __device__ __forceinline__ int intersect_slab_impl(const HotSlabN<NS>& h, v3 o, v3 d, float& t_out, bool shadow_skip_planes,
                                                    const float* occ,       // occ[i] = dot(c_i - o, c_i - o) and
                                                    const v3* oc_at_o) {    // oc_at_o[i] = c_i - o if the caller has them
@@ -401,11 +401,11 @@ __device__ __forceinline__ int intersect_slab_impl(const HotSlabN<NS>& h, v3 o, 
     if constexpr (Closed) return id;
     return (t < h.inf) ? id : -1;                                            // :336
 }
-template <bool Fast, bool Closed = false, bool OccR2 = false, int StatsBase = -1, int NS = 3>
+template <int Fast, bool Closed = false, bool OccR2 = false, int StatsBase = -1, int NS = 3>
 __device__ __forceinline__ int intersect_slab(const HotSlabN<NS>& h, v3 o, v3 d, float& t_out, bool shadow_skip_planes) {
     return intersect_slab_impl<Fast, Closed, OccR2, StatsBase, false, NS>(h, o, d, t_out, shadow_skip_planes, nullptr, nullptr);
 }
-template <bool Fast, bool Closed = false, bool OccR2 = false, int StatsBase = -1, int NS = 3>
+template <int Fast, bool Closed = false, bool OccR2 = false, int StatsBase = -1, int NS = 3>
 __device__ __forceinline__ int intersect_slab(const HotSlabN<NS>& h, v3 o, v3 d, float& t_out, bool shadow_skip_planes,
                                               const float* occ, const v3* oc_at_o) {
     return intersect_slab_impl<Fast, Closed, OccR2, StatsBase, true, NS>(h, o, d, t_out, shadow_skip_planes, occ, oc_at_o);
@@ -416,7 +416,7 @@ __device__ __forceinline__ int intersect_slab(const HotSlabN<NS>& h, v3 o, v3 d,
 // The reference keeps a later candidate only if it is STRICTLY nearer, so sphere li wins iff its root dd_li is finite,
 // strictly below every root of the spheres before it and not above any root of the spheres after it.  dd_k is the value the
 // loop assigns for sphere k (:319-327), 1e20 when there is none.  Same comparisons on the same values: exact.
-template <bool Fast, bool OccR2 = false, int NS = 3>   // OccR2: occ[i] holds |c_i - o|^2 - r_i^2 (the fast pool kernel's form)
+template <int Fast, bool OccR2 = false, int NS = 3>   // OccR2: occ[i] holds |c_i - o|^2 - r_i^2 (the fast pool kernel's form)
 __device__ __forceinline__ bool shadow_reaches_sphere(const HotSlabN<NS>& h, v3 o, v3 d, int li, v3 oc_li, const float* occ) {
     MC_PT_DECISION_FP
     float dd[NS];
@@ -506,7 +506,7 @@ __device__ __forceinline__ bool shadow_visible_disjoint(const HotSlabN<NS>& h, v
 // it reaches any wall, orders of magnitude beyond fp32 rounding of either quotient, so no plane can win `dd < t`
 // against that hit; when the ray misses the light the answer is "not sphere i" with or without the planes.  The
 // sphere loop is unchanged, hence the same id among spheres.
-template <bool Fast, int NP, int NS, bool Slab, int Prec>
+template <int Fast, int NP, int NS, bool Slab, int Prec>
 __device__ __forceinline__ int intersect(const SceneArgs& sc, const float* __restrict__ obj, v3 o, v3 d, float& t_out,
                                          bool shadow_skip_planes = false) {
     MC_PT_DECISION_FP
@@ -610,7 +610,7 @@ __device__ __forceinline__ void stage_records(float* lds_obj, const float* __res
 
 // ---- pieces of one sample shared by the round-synchronous kernels (trace_sample) and the sample-pool kernel (pathtrace_pool.h) --
 // Camera ray through the sensor sample of (pixel, samp) — pathTracer.comp:357-362; returns the direction (the origin is a.lc).
-template <bool Fast> __device__ __forceinline__ v3 camera_ray(const PTArgs& a, uint32_t gx, uint32_t gy, uint32_t samp) {
+template <int Fast> __device__ __forceinline__ v3 camera_ray(const PTArgs& a, uint32_t gx, uint32_t gy, uint32_t samp) {
     v3 r0 = rand01(gx, gy, samp);
     float rnd2x = 2.0f * r0.x, rnd2y = 2.0f * r0.y;
     // :358-:359 tent filter: one sqrt of the selected argument instead of one per branch (the same value either way)
@@ -625,7 +625,7 @@ template <bool Fast> __device__ __forceinline__ v3 camera_ray(const PTArgs& a, u
     return normalize<Fast>(a.lc - spos);                                  // :362
 }
 // Direction towards a point of the light's visible cap (:408-:413): xc = light centre - x, xcc = |xc|^2, lr2 = radius^2.
-template <bool Fast> __device__ __forceinline__ v3 light_sample_direction(v3 xc, float xcc, float lr2, v3 rnd, float& cos_a_max) {
+template <int Fast> __device__ __forceinline__ v3 light_sample_direction(v3 xc, float xcc, float lr2, v3 rnd, float& cos_a_max) {
     const float inv_len = dm::inversesqrt<Fast>(xcc);
     v3 sw = xc * inv_len;                                     // :409 normalize(xc)
     if constexpr (Fast && MC_PT_FAST_TANGENT_ONE_RSQ) {
@@ -636,12 +636,12 @@ template <bool Fast> __device__ __forceinline__ v3 light_sample_direction(v3 xc,
         const bool sel = __builtin_fabsf(sw.x) > 0.1f;
         const float q = sel ? sw.x : sw.y;
         const float B = __builtin_fmaf(q, q, sw.z * sw.z);
-        cos_a_max = dm::fsqrt<true>(1.0f - lr2 * (inv_len * inv_len));        // :410
+        cos_a_max = dm::fsqrt<Fast>(1.0f - lr2 * (inv_len * inv_len));        // :410
         const float cos_a = (1.0f - rnd.x) + rnd.x * cos_a_max;               // :411
         const float A = __builtin_fmaxf(1.0f - cos_a * cos_a, 1e-30f);
-        const float g = A * dm::inversesqrt<true>(A * B);
+        const float g = A * dm::inversesqrt<Fast>(A * B);
         float sphi, cphi;
-        dm::sincos_angle<true>(0.0f, rnd.y, sphi, cphi);                      // :412
+        dm::sincos_angle<Fast>(0.0f, rnd.y, sphi, cphi);                      // :412
         if (MC_PT_FAST_FRAME_NO_CROSS) {
             // t1 = (z, 0, -x) or (0, -z, y) has a zero component and t2 = cross(sw, t1) = (-xy, B, -yz) or (B, -xy, -xz) carries B
             // itself, so a t1 + b t2 + c sw needs no cross product: with m = the axis component (y or x), q the other one,
@@ -653,13 +653,13 @@ template <bool Fast> __device__ __forceinline__ v3 light_sample_direction(v3 xc,
             const float sa = sel ? a : -a;
             const float first = __builtin_fmaf(sa, sw.z, q * cm), lz = __builtin_fmaf(-sa, q, sw.z * cm);
             const v3 lv{sel ? first : sp, sel ? sp : first, lz};              // :413
-            if constexpr (MC_PT_FAST_RENORMALISE != 0) return normalize<true>(lv);
+            if constexpr (Fast == 2 || MC_PT_FAST_RENORMALISE != 0) return normalize<Fast>(lv);
             return lv;
         }
         const v3 t1{sel ? sw.z : 0.0f, sel ? 0.0f : -sw.z, sel ? -q : q};
         const v3 t2 = cross(sw, t1);
         const v3 lv = (t1 * (cphi * g) + t2 * (sphi * g)) + sw * cos_a;       // :413
-        if constexpr (MC_PT_FAST_RENORMALISE != 0) return normalize<true>(lv);
+        if constexpr (Fast == 2 || MC_PT_FAST_RENORMALISE != 0) return normalize<Fast>(lv);
         return lv;
     }
     v3 su = tangent_u<Fast>(sw);
@@ -677,7 +677,7 @@ template <bool Fast> __device__ __forceinline__ v3 light_sample_direction(v3 xc,
 }
 // Cosine-weighted bounce around w = nl (:426-:428).  Unit: w is of unit length (slab kernels: +-1 axis normals, normalised sphere
 // normals); a generic scene's plane normal is used as given, and there :428's normalize is not an identity.
-template <bool Fast, bool Unit> __device__ __forceinline__ v3 cosine_bounce(v3 w, v3 rnd) {
+template <int Fast, bool Unit> __device__ __forceinline__ v3 cosine_bounce(v3 w, v3 rnd) {
     float r1 = (2.0f * kPi) * rnd.x, r2 = rnd.y, r2s = dm::fsqrt<Fast>(r2);   // :426
     v3 u = tangent_u<Fast>(w);                                    // :427
     v3 v = cross(w, u);
@@ -696,7 +696,7 @@ template <bool Fast, bool Unit> __device__ __forceinline__ v3 cosine_bounce(v3 w
 // form's; such a component multiplies t and is added to a non-zero coordinate, or fails the |d_a| > 1e-7 test of :119.)
 // `id` = the wall's slab id 2a + (normal is +e_a); a hit wall faces the ray (:119: dot(d, n) > 0), so nl = -n and sigma is
 // negative exactly for the odd ids.   a = 0: (sC, B, -sA)   a = 1: (B, sC, sA)   a = 2: (B, -sA, sC)   with sX = sigma * X.
-template <bool Fast> __device__ __forceinline__ v3 cosine_bounce_wall(int id, v3 rnd) {
+template <int Fast> __device__ __forceinline__ v3 cosine_bounce_wall(int id, v3 rnd) {
     const float r1 = (2.0f * kPi) * rnd.x, r2 = rnd.y, r2s = dm::fsqrt<Fast>(r2);   // :426
     float s1, c1;
     dm::sincos_angle<Fast>(r1, rnd.x, s1, c1);
@@ -712,7 +712,7 @@ template <bool Fast> __device__ __forceinline__ v3 cosine_bounce_wall(int id, v3
 // Mirror / glass bounce in the fast slab form (:432-:447): every outcome is rd*alpha + n*beta — reflection (1, -2 dot(n, rd)),
 // refraction (nnt, -k) — so the scalars are selected and ONE direction is formed; cos of the leaving ray = sqrt(cos2t), c^5
 // through c^2.  mat is 2 or 3; dot_n_rd = dot(n, rd); rx = rnd.x; accmat receives :445's weight.
-__device__ __forceinline__ v3 specular_bounce_fast(int mat, v3 rd, v3 n, float dot_n_rd, float rx, v3& accmat) {
+template <int Fast> __device__ __forceinline__ v3 specular_bounce_fast(int mat, v3 rd, v3 n, float dot_n_rd, float rx, v3& accmat) {
     MC_PT_DECISION_FP
     float alpha = 1.0f, beta = -2.0f * dot_n_rd;
     if (mat == 3) {
@@ -723,24 +723,24 @@ __device__ __forceinline__ v3 specular_bounce_fast(int mat, v3 rd, v3 n, float d
         const float cos2t = 1.0f - (nnt * nnt) * (1.0f - a_dn * a_dn);    // :440
         if (cos2t >= 0.0f) {
             MC_REGION(7);
-            const float sq2t = dm::fsqrt<true>(cos2t);
+            const float sq2t = dm::fsqrt<Fast>(cos2t);
             const float k = (into ? 1.0f : -1.0f) * (sq2t - a_dn * nnt);  // :441
             const float c = 1.0f - (into ? a_dn : sq2t), c2 = c * c;
             const float Re = 0.04f + 0.96f * ((c2 * c2) * c);              // :442-:443, R0 = (0.5/2.5)^2
             const float P = 0.25f + 0.5f * Re;
             const bool pick_refl = rx < P;                                // :444
-            accmat = accmat * dm::fdiv<true>(pick_refl ? Re : 1.0f - Re, pick_refl ? P : 1.0f - P);   // :445
+            accmat = accmat * dm::fdiv<Fast>(pick_refl ? Re : 1.0f - Re, pick_refl ? P : 1.0f - P);   // :445
             if (!pick_refl) { alpha = nnt; beta = -k; }
         }
     }
     const v3 out = rd * alpha + n * beta;
-    if constexpr (MC_PT_FAST_RENORMALISE != 0) return normalize<true>(out);
+    if constexpr (Fast == 2 || MC_PT_FAST_RENORMALISE != 0) return normalize<Fast>(out);   // (:441 normalises the refracted ray)
     return out;
 }
 
 // Mirror / glass bounce in the general form (:432-:447) — the strict kernels (literal operation order) and the fast generic
 // kernel.  mat is 2 or 3; nl as :390; dot_n_rd = dot(n, rd) (fast only); rx = rnd.x; accmat receives :445's weight.
-template <bool Fast, bool Slab>
+template <int Fast, bool Slab>
 __device__ __forceinline__ v3 specular_bounce_general(int mat, v3 rd, v3 n, v3 nl, float dot_n_rd, float rx, v3& accmat) {
     MC_PT_DECISION_FP
     const v3 refl = reflect(rd, n);
@@ -784,7 +784,7 @@ __device__ __forceinline__ v3 specular_bounce_general(int mat, v3 rd, v3 n, v3 n
 template <bool Slab, int NS> constexpr int slab_spheres() { return Slab && NS > 0 ? NS : 1; }
 
 // One sample: returns accrad (pathTracer.comp:356-449).  Box (fast math, slab scenes with SceneArgs::box_ok): see above.
-template <bool Fast, int NP, int NS, bool Slab, int Prec, bool Box = false>
+template <int Fast, int NP, int NS, bool Slab, int Prec, bool Box = false>
 __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restrict__ lds_obj,
                                            const uint32_t* __restrict__ lds_emissive, const HotSlabN<slab_spheres<Slab, NS>()>& hot,
                                            uint32_t gx, uint32_t gy, uint32_t samp) {
@@ -925,7 +925,7 @@ __device__ __forceinline__ v3 trace_sample(const PTArgs& a, const float* __restr
             MC_PT_DECISION_FP
             MC_REGION(5);   // mirror direction = the glass block's reflected direction
             if constexpr (Fast && Slab) {
-                rd = specular_bounce_fast(mat, rd, n, dot_n_rd, rnd.x, accmat);   // (the fast slab form, see there)
+                rd = specular_bounce_fast<Fast>(mat, rd, n, dot_n_rd, rnd.x, accmat);   // (the fast slab form, see there)
             } else {
             rd = specular_bounce_general<Fast, Slab>(mat, rd, n, nl, dot_n_rd, rnd.x, accmat);
             }   // (general form)
@@ -959,11 +959,11 @@ template <int S> constexpr uint32_t block_h() { return 2u * WaveTile<S>::h; }
 
 // Waves per SIMD the register budget is set for: 6 / 5 (fast / strict) for the generic kernels and the reference's three spheres;
 // a slab scene with more spheres keeps five more values per sphere live across a bounce (and leaves its constants to the scalar file).
-template <bool Fast, bool Slab, int NS> constexpr int rounds_waves() {
+template <int Fast, bool Slab, int NS> constexpr int rounds_waves() {
     return (!Slab || NS <= 3) ? (Fast ? 6 : 5) : NS <= 5 ? (Fast ? 5 : 4) : (Fast ? 4 : 3);
 }
 
-template <bool Fast, int NP, int NS, bool Slab, int S, int Prec, bool Box = false>
+template <int Fast, int NP, int NS, bool Slab, int S, int Prec, bool Box = false>
 __global__ void __launch_bounds__(256, (rounds_waves<Fast, Slab, NS>())) pathtrace_kernel(PTArgs a) {
     // dynamic LDS (no static __shared__ in front: the base stays 16-B aligned): [records | emissive list]
     extern __shared__ float lds_dyn[];
@@ -1057,6 +1057,7 @@ __global__ void __launch_bounds__(256, (rounds_waves<Fast, Slab, NS>())) pathtra
 // variant 4 = the sample-pool kernels (pathtrace_pool.h; closed-box slab scenes), variant 5 = generic, scene read from memory.
 // variant 3 = the closed-box fast kernel (slab scenes with SceneArgs::box_ok, fast math only).
 int launch_fast(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s);
+int launch_careful(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s);   // pathtrace_careful.hip: tier 2
 int launch_strict(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s);
 
 inline size_t scene_lds_bytes(const PTArgs& a) {
@@ -1068,7 +1069,7 @@ constexpr size_t kMaxSceneLdsBytes = 144u * 1024u;   // of the 160 KB per CU: 30
 // memory 0.27-0.30 whatever the size — the LDS copy wins while four blocks fit a CU's 160 KB.
 constexpr size_t kSceneLdsAutoBytes = 36u * 1024u;
 
-template <bool Fast, int NP, int NS, bool Slab, int S, int Prec, bool Box = false>
+template <int Fast, int NP, int NS, bool Slab, int S, int Prec, bool Box = false>
 inline int launch_one(const PTArgs& a, uint32_t tile_rows, hipStream_t s) {
     dim3 grid((a.W + block_w<S>() - 1u) / block_w<S>(), (tile_rows + block_h<S>() - 1u) / block_h<S>());
     size_t lds = NP == -2 ? 0u : scene_lds_bytes(a);
@@ -1086,14 +1087,14 @@ inline int launch_one(const PTArgs& a, uint32_t tile_rows, hipStream_t s) {
 
 // The slab kernels (6 axis-aligned planes + NS spheres, NS = 1 .. kMaxSlabSpheres: one instantiation per count, the sphere loops
 // unrolled over VGPR-resident centres) at width S.
-template <bool Fast, bool Box, int NS>
+template <int Fast, bool Box, int NS>
 inline int launch_slab_width(const PTArgs& a, int S, uint32_t tile_rows, hipStream_t s) {
     if (S == 1) return launch_one<Fast, 6, NS, true, 1, 0, Box>(a, tile_rows, s);
     if (S == 4) return launch_one<Fast, 6, NS, true, 4, 0, Box>(a, tile_rows, s);
     if (S == 16) return launch_one<Fast, 6, NS, true, 16, 0, Box>(a, tile_rows, s);
     return MC_ERR_INVALID_ARGUMENT;
 }
-template <bool Fast, bool Box>
+template <int Fast, bool Box>
 inline int launch_slab(const PTArgs& a, int S, uint32_t tile_rows, hipStream_t s) {
     switch (a.scene.n_spheres) {
         case 1: return launch_slab_width<Fast, Box, 1>(a, S, tile_rows, s);
@@ -1108,7 +1109,7 @@ inline int launch_slab(const PTArgs& a, int S, uint32_t tile_rows, hipStream_t s
     }
 }
 
-template <bool Fast>
+template <int Fast>
 inline int launch_impl(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s) {
     if (prec == 0) {
         if constexpr (Fast) {

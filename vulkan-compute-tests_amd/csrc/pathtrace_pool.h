@@ -69,17 +69,17 @@ constexpr uint32_t kPoolStashFloats = 128u * kPoolEntryFloats;     // per wave: 
 #endif
 template <int NS> constexpr uint32_t pool_result_batches() { return MC_PT_POOL_RESULT_BATCHES ? MC_PT_POOL_RESULT_BATCHES : (NS <= 3 ? 3u : 4u); }
 template <int NS> constexpr uint32_t pool_result_floats() { return 64u * pool_result_batches<NS>() * 3u; }   // per wave: 64/S pixels x batches x S samples x 3
-template <bool Fast, int NS> constexpr uint32_t pool_wave_lds_floats() { return kPoolStashFloats + (Fast ? 0u : pool_result_floats<NS>()); }
-template <bool Fast, int NS> constexpr size_t pool_block_lds_bytes() { return (pool_record_floats<NS>() + 4u * pool_wave_lds_floats<Fast, NS>()) * sizeof(float); }
+template <int Fast, int NS> constexpr uint32_t pool_wave_lds_floats() { return kPoolStashFloats + (Fast ? 0u : pool_result_floats<NS>()); }
+template <int Fast, int NS> constexpr size_t pool_block_lds_bytes() { return (pool_record_floats<NS>() + 4u * pool_wave_lds_floats<Fast, NS>()) * sizeof(float); }
 // Waves per SIMD the register budget is set for: 7 / 6 for the reference's three spheres (72 / 80 VGPRs); every further sphere
 // keeps five more values live across a bounce (c_i - x, |c_i - x|^2 and its r^2-reduced form), so the budget widens with the count.
-template <bool Fast, int NS> constexpr int pool_waves() {
+template <int Fast, int NS> constexpr int pool_waves() {
     return Fast ? (NS <= 3 ? MC_PT_POOL_WAVES : NS <= 5 ? 6 : NS <= 6 ? 5 : 4) : (NS <= 3 ? MC_PT_POOL_STRICT_WAVES : NS <= 6 ? 4 : 3);
 }
 
 // Disjoint (fast math): the host proved the spheres pairwise disjoint — shadow rays are decided without square roots
 // (shadow_visible_disjoint); false: overlapping spheres, the root form (shadow_reaches_sphere).  The strict kernel has one form.
-template <bool Fast, int S, int NS, bool Disjoint = true>
+template <int Fast, int S, int NS, bool Disjoint = true>
 __global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_kernel(PTArgs a) {
     constexpr uint32_t kPoolRecordFloats = pool_record_floats<NS>();
     extern __shared__ float lds_dyn[];
@@ -105,7 +105,10 @@ __global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_
     __syncthreads();
     // fast math: the sphere tests of a bounce (three of the shadow ray, three of the next ray, all from the hit point x) read
     // |c_i - x|^2 - r_i^2, formed once, instead of each adding r_i^2 to its b^2 - |c_i - x|^2
-    constexpr bool kOccR2 = Fast && MC_PT_FAST_OCC_MINUS_R2;
+    // (fast tier only.  The careful tier keeps the reference's order (b^2 - |c - x|^2) + r^2: of the identities of exact arithmetic fast
+    // math does not execute, this one and the un-normalised directions are the two whose forked samples do not balance — more of them
+    // lose radiance than gain it; with both in the reference's form gains and losses cancel: profiles/r05_fork_bias_identities.txt)
+    constexpr bool kOccR2 = Fast == 1 && MC_PT_FAST_OCC_MINUS_R2;
     constexpr uint32_t TW = WaveTile<S>::w, TH = WaveTile<S>::h, Ring = 2u * (uint32_t)S, RRing = pool_result_batches<NS>() * (uint32_t)S;
     HotSlabN<NS> hot;
     hot.template load<MC_PT_POOL_HOT_VGPR, MC_PT_POOL_HOT_W>(a.scene);   // (uniform operands: this kernel has no vector registers to spare for copies)
@@ -221,7 +224,7 @@ __global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_
                     oc0[i] = v3{a.cam_oc[i][0], a.cam_oc[i][1], a.cam_oc[i][2]};
                     occ0[i] = kOccR2 ? a.cam_occ[i] - hot.r2[i] : a.cam_occ[i];
                 }
-                int cid = intersect_slab<Fast, Fast, kOccR2, 22>(hot, a.lc, crd, ct, false, occ0, oc0);
+                int cid = intersect_slab<Fast, (Fast != 0), kOccR2, 22>(hot, a.lc, crd, ct, false, occ0, oc0);
                 // nothing to trace: a pixel outside the tile, a sample beyond the range; a camera ray that misses everything (:369)
                 // gathers nothing either
                 if (!((MC_PT_POOL_KEEP_VALID ? pixel_valid : g.valid) && samp < a.sample_end)) cid = -1;
@@ -331,7 +334,7 @@ __global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_
                     emissive = 0.0f;                                              // :429
                 } else {                                                          // :432 mirror, :437 glass (box_ok: 2 or 3)
                     MC_REGION(11);   // mirror / glass
-                    if constexpr (Fast) rd = specular_bounce_fast(mat, rd, n, dot_n_rd, rnd.x, accmat);
+                    if constexpr (Fast) rd = specular_bounce_fast<Fast>(mat, rd, n, dot_n_rd, rnd.x, accmat);
                     else rd = specular_bounce_general<false, true>(mat, rd, n, nl, dot_n_rd, rnd.x, accmat);
                     emissive = 1.0f;                                              // :447
                 }
@@ -339,7 +342,7 @@ __global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_
                 go = key != kend;                                                 // :367 depth limit
                 if (go) {
                     MC_REGION(14);   // intersection of the next depth
-                    id = intersect_slab<Fast, Fast, kOccR2, 16>(hot, ro, rd, t, false, occ, xoc);
+                    id = intersect_slab<Fast, (Fast != 0), kOccR2, 16>(hot, ro, rd, t, false, occ, xoc);
                     go = id >= 0;                                                 // :369
                 }
                 if (go) {                                                         // the next bounce's random numbers and roulette
@@ -408,7 +411,7 @@ __global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_
     if (fin.valid && fin.sub == 0u) a.out[(size_t)fin.ty * a.W + gx] = sum;
 }
 
-template <bool Fast, int S, int NS> inline int launch_pool_one(const PTArgs& a, uint32_t tile_rows, hipStream_t s) {
+template <int Fast, int S, int NS> inline int launch_pool_one(const PTArgs& a, uint32_t tile_rows, hipStream_t s) {
     dim3 grid((a.W + block_w<S>() - 1u) / block_w<S>(), (tile_rows + block_h<S>() - 1u) / block_h<S>());
     constexpr size_t lds = pool_block_lds_bytes<Fast, NS>();
     if (Fast && (!a.scene.spheres_disjoint || MC_PT_FAST_NO_DISJOINT)) hipLaunchKernelGGL((pathtrace_pool_kernel<Fast, S, NS, false>), grid, dim3(256), lds, s, a);
@@ -417,7 +420,7 @@ template <bool Fast, int S, int NS> inline int launch_pool_one(const PTArgs& a, 
 }
 // variant 4 of launch_fast / launch_strict: 16 lanes per pixel and batch (the host never passes anything else); one instantiation
 // per sphere count 1 .. kMaxSlabSpheres
-template <bool Fast> inline int launch_pool(const PTArgs& a, int S, uint32_t tile_rows, hipStream_t s) {
+template <int Fast> inline int launch_pool(const PTArgs& a, int S, uint32_t tile_rows, hipStream_t s) {
     if (S != 16) return MC_ERR_INVALID_ARGUMENT;
     switch (a.scene.n_spheres) {
         case 1: return launch_pool_one<Fast, 16, 1>(a, tile_rows, s);

@@ -47,13 +47,14 @@ void HostStorage::allocate(uint64_t bytes) {
         if (d && d[0]) msg += std::string(" (") + d + ")";
         throw std::runtime_error(msg);
     }
-    ptr_ = static_cast<float*>(p);
-    floats_ = (size_t)(bytes / sizeof(float));
+    ptr_ = p;
+    bytes_ = (size_t)bytes;
 }
 
 void ComputeApp::createBuffer(uint64_t bufferSizeBytes) {
     auto t0 = std::chrono::steady_clock::now();
-    buffer.allocate(bufferSizeBytes);
+    if (gpuPostprocess) rgba8.allocate(bufferSizeBytes / 4);   // 16 B/pixel of fp32 -> 4 B/pixel of RGBA8
+    else buffer.allocate(bufferSizeBytes);
     times.allocMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 

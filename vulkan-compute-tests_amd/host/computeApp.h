@@ -29,17 +29,20 @@ public:
     HostStorage& operator=(const HostStorage&) = delete;
     ~HostStorage() { release(); }
     void allocate(uint64_t bytes);             // throws std::runtime_error; the contents are unspecified until run() has filled them
-    void release() { if (ptr_) mc_host_free(ptr_); ptr_ = nullptr; floats_ = 0; }
-    float* data() { return ptr_; }
-    const float* data() const { return ptr_; }
-    size_t size() const { return floats_; }    // in floats
-    bool empty() const { return floats_ == 0; }
-    const float* begin() const { return ptr_; }
-    const float* end() const { return ptr_ + floats_; }
-    float operator[](size_t i) const { return ptr_[i]; }
+    void release() { if (ptr_) mc_host_free(ptr_); ptr_ = nullptr; bytes_ = 0; }
+    float* data() { return static_cast<float*>(ptr_); }
+    const float* data() const { return static_cast<const float*>(ptr_); }
+    uint8_t* bytes() { return static_cast<uint8_t*>(ptr_); }
+    const uint8_t* bytes() const { return static_cast<const uint8_t*>(ptr_); }
+    size_t size() const { return bytes_ / sizeof(float); }   // in floats
+    size_t sizeBytes() const { return bytes_; }
+    bool empty() const { return bytes_ == 0; }
+    const float* begin() const { return data(); }
+    const float* end() const { return data() + size(); }
+    float operator[](size_t i) const { return data()[i]; }
 private:
-    float* ptr_ = nullptr;
-    size_t floats_ = 0;
+    void* ptr_ = nullptr;
+    size_t bytes_ = 0;
 };
 
 struct ComputeApp {
@@ -77,7 +80,8 @@ struct ComputeApp {
     const Timing& timing() const { return times; }
 
 protected:
-    void createBuffer(uint64_t bufferSizeBytes);   // vulkanComputeApp.cpp:489-533: the output storage buffer
+    void createBuffer(uint64_t bufferSizeBytes);   // vulkanComputeApp.cpp:489-533: the output storage buffer (gpuPostprocess: a quarter
+                                                   // of it, for the RGBA8 image)
     static void check(int status, const char* what);
 
     mc_context* ctx = nullptr;
@@ -87,7 +91,8 @@ protected:
     bool quiet = false;
     bool gpuPostprocess = false;
     int pngThreads = 0;
-    std::vector<uint8_t> rgba8;   // filled by run() when gpuPostprocess is on
+    HostStorage rgba8;            // gpuPostprocess: the RGBA8 image run() fills (page-locked too: 4 B/pixel cross PCIe), allocated by
+                                  // preRun INSTEAD of the 16-B/pixel storage buffer, which such a run never copies to the host
     double lastRunMs = 0.0;
     Timing times;
     // The storage buffer, host side: vec4 fp32 per pixel, row-major (what vkMapMemory exposes to

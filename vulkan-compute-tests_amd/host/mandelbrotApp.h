@@ -42,9 +42,8 @@ struct MandelbrotApp : public ComputeApp {
 
     virtual void runCommandBuffer() override {
         if (gpuPostprocess) {   // render + float->u8 on the device: 4 B/pixel cross PCIe instead of 16
-            rgba8.resize((size_t)resx * resy * 4);
-            if (multi) check(mc_multi_mandelbrot_render_rgba8(multi, &params, rgba8.data()), "mc_multi_mandelbrot_render_rgba8");
-            else check(mc_mandelbrot_render_rgba8(ctx, &params, rgba8.data()), "mc_mandelbrot_render_rgba8");
+            if (multi) check(mc_multi_mandelbrot_render_rgba8(multi, &params, rgba8.bytes()), "mc_multi_mandelbrot_render_rgba8");
+            else check(mc_mandelbrot_render_rgba8(ctx, &params, rgba8.bytes()), "mc_mandelbrot_render_rgba8");
             return;
         }
         if (multi) check(mc_multi_mandelbrot_render(multi, &params, buffer.data(), nullptr), "mc_multi_mandelbrot_render");
@@ -61,11 +60,10 @@ struct MandelbrotApp : public ComputeApp {
         std::vector<uint8_t> image;
         constexpr float scaleFactor = 255.0f;   // mandelbrotApp.h:174
         auto t0 = std::chrono::steady_clock::now();
-        if (gpuPostprocess) image.swap(rgba8);  // already converted on the device with the same cast semantics
-        else getRenderedImage(image, resx, resy, scaleFactor);
+        if (!gpuPostprocess) getRenderedImage(image, resx, resy, scaleFactor);   // (else: converted on the device, same cast semantics)
         auto t1 = std::chrono::steady_clock::now();
         printf("writing %s\n", png_filename);
-        std::string err = writePng(png_filename, image.data(), resx, resy);
+        std::string err = writePng(png_filename, gpuPostprocess ? rgba8.bytes() : image.data(), resx, resy);
         if (!err.empty()) printf("encoder error: %s", err.c_str());   // printed, not thrown (mandelbrotApp.h:183)
         times.convertMs = std::chrono::duration<double, std::milli>(t1 - t0).count();
         times.pngMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();

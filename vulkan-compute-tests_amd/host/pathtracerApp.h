@@ -81,11 +81,10 @@ struct PathtracerApp : public ComputeApp {
 
     virtual void runCommandBuffer() override {
         if (gpuPostprocess) {   // render + float->u8 + 180-degree rotation on the device (pathtracerApp.h:202-243)
-            rgba8.resize((size_t)resx * resy * 4);
             const uint32_t np = (uint32_t)planes.size() / 12, ns = (uint32_t)spheres.size() / 12;
-            if (multi) check(mc_multi_pathtrace_render_rgba8(multi, &params, planes.data(), np, spheres.data(), ns, rgba8.data()),
+            if (multi) check(mc_multi_pathtrace_render_rgba8(multi, &params, planes.data(), np, spheres.data(), ns, rgba8.bytes()),
                              "mc_multi_pathtrace_render_rgba8");
-            else check(mc_pathtrace_render_rgba8(ctx, &params, planes.data(), np, spheres.data(), ns, rgba8.data()),
+            else check(mc_pathtrace_render_rgba8(ctx, &params, planes.data(), np, spheres.data(), ns, rgba8.bytes()),
                        "mc_pathtrace_render_rgba8");
             return;
         }
@@ -107,16 +106,14 @@ struct PathtracerApp : public ComputeApp {
         constexpr float scaleFactor = 1.0f;   // pathtracerApp.h:227
         printf("writing %s\n", png_filename);
         auto t0 = std::chrono::steady_clock::now();
-        if (gpuPostprocess) {
-            image.swap(rgba8);   // converted and rotated on the device
-        } else {
+        if (!gpuPostprocess) {   // (else: converted and rotated on the device)
             // getRenderedImage, then: due to the pinhole camera the image is upside-down and mirrored — undo that (pathtracerApp.h:235-243:
             // every pixel of the left half swapped with its point reflection).  One pass here: each converted pixel is written to the
             // place the swap loop would leave it in (the same bytes, incl. an odd width's untouched middle column).
             convertStorage(image, resx, resy, scaleFactor, true);
         }
         auto t1 = std::chrono::steady_clock::now();
-        std::string err = writePng(png_filename, image.data(), resx, resy);
+        std::string err = writePng(png_filename, gpuPostprocess ? rgba8.bytes() : image.data(), resx, resy);
         if (!err.empty()) printf("encoder error: %s", err.c_str());
         times.convertMs = std::chrono::duration<double, std::milli>(t1 - t0).count();
         times.pngMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
