@@ -180,6 +180,25 @@ def test_host_x86_cast_matches_oracle(hostutil, O):
     assert np.array_equal(out, O.float_to_rgba8(quad, 1.0)[:, 0])
 
 
+def test_host_storage_conversion_equals_the_reference_loops(hostutil, O):
+    """The apps' host post-process (round 5: row stripes on all cores, conversion and rotation in ONE pass) against the reference's two
+    serial loops as the oracle restates them — getRenderedImage's cast (mandelbrotApp.h:159-166, pathtracerApp.h:212-219; x86-64 semantics
+    for out-of-range values) and the 180-degree swap loop with its odd-width middle column (pathtracerApp.h:236-243) — for even and odd
+    widths, heights below and above one stripe per thread, 1 / 3 / all threads."""
+    hostutil.mcu_convert_storage.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_int]
+    rng = np.random.default_rng(7)
+    for (w, h) in ((64, 48), (51, 34), (7, 5), (333, 211), (1, 40), (2, 17)):
+        buf = rng.uniform(-40.0, 300.0, (h, w, 4)).astype(np.float32)
+        buf[rng.integers(h), rng.integers(w), :3] = (np.nan, np.inf, -3.0e9)
+        for scale in (1.0, 255.0):
+            plain = O.float_to_rgba8(buf, scale).reshape(h, w, 4)
+            for rotate, expect in ((0, plain), (1, O.rotate180(plain, w, h))):
+                for threads in (1, 3, 0):
+                    out = np.zeros((h, w, 4), np.uint8)
+                    hostutil.mcu_convert_storage(buf.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), w, h, scale, rotate, threads)
+                    assert np.array_equal(out, expect), (w, h, scale, rotate, threads)
+
+
 def test_apps_report_missing_device_like_the_reference(B):
     """main.cpp:35-38: a std::runtime_error is printed and the process exits with EXIT_FAILURE.  On the CPU-only
     container the apps have no device: they must say so and fail (no silent fallback)."""

@@ -59,28 +59,8 @@ void ComputeApp::createBuffer(uint64_t bufferSizeBytes) {
 }
 
 void ComputeApp::convertStorage(std::vector<uint8_t>& image, uint32_t resx, uint32_t resy, float scale, bool rotate180) const {
-    struct Pixel { float r, g, b, a; };
-    const Pixel* p = reinterpret_cast<const Pixel*>(buffer.data());
     image.resize((size_t)resx * resy * 4);
-    uint8_t* out = image.data();
-    // Destination pixel of source pixel (x, y) under the reference's swap loop: every pixel with x < resx / 2 changes places with its
-    // point reflection; for an odd width the middle column (x = resx / 2) is left where it is (pathtracerApp.h:238: `x < resx / 2`).
-    auto rows = [&](uint32_t y0, uint32_t y1) {
-        for (uint32_t y = y0; y < y1; y++)
-            for (uint32_t x = 0; x < resx; x++) {
-                const Pixel& s = p[(size_t)y * resx + x];
-                size_t to = (size_t)y * resx + x;
-                if (rotate180 && !((resx & 1u) && x == resx / 2)) to = (size_t)(resy - 1 - y) * resx + (resx - 1 - x);
-                uint8_t* o = out + 4 * to;
-                o[0] = x86FloatToU8(scale * s.r); o[1] = x86FloatToU8(scale * s.g); o[2] = x86FloatToU8(scale * s.b); o[3] = 255u;
-            }
-    };
-    unsigned n = pngThreads > 0 ? (unsigned)pngThreads : std::thread::hardware_concurrency();
-    n = std::max(1u, std::min(n, std::max(1u, resy / 16u)));
-    if (n == 1) { rows(0, resy); return; }
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < n; t++) th.emplace_back(rows, (uint32_t)((uint64_t)resy * t / n), (uint32_t)((uint64_t)resy * (t + 1) / n));
-    for (auto& t : th) t.join();
+    pngwriter::convertStorage(buffer.data(), image.data(), resx, resy, scale, rotate180, pngThreads);
 }
 
 void ComputeApp::run() {

@@ -26,4 +26,9 @@ void mcu_float_to_u8(const float* in, uint8_t* out, size_t n) {
     for (size_t i = 0; i < n; i++) out[i] = x86FloatToU8(in[i]);
 }
 
+// The apps' storage-buffer -> RGBA8 conversion (+ the path tracer's 180-degree rotation), row stripes on `threads` host threads.
+void mcu_convert_storage(const float* vec4, uint8_t* rgba8, uint32_t w, uint32_t h, float scale, int rotate180, int threads) {
+    pngwriter::convertStorage(vec4, rgba8, w, h, scale, rotate180 != 0, threads);
+}
+
 }  // extern "C"

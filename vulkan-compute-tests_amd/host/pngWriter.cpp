@@ -176,4 +176,26 @@ std::string encodeFile(const char* filename, const uint8_t* rgba8, uint32_t w, u
     return n == png.size() ? "" : "short write";
 }
 
+
+void convertStorage(const float* vec4, uint8_t* rgba8, uint32_t w, uint32_t h, float scale, bool rotate180, int threads) {
+    struct Pixel { float r, g, b, a; };
+    const Pixel* p = reinterpret_cast<const Pixel*>(vec4);
+    auto rows = [=](uint32_t y0, uint32_t y1) {
+        for (uint32_t y = y0; y < y1; y++)
+            for (uint32_t x = 0; x < w; x++) {
+                const Pixel& s = p[(size_t)y * w + x];
+                size_t to = (size_t)y * w + x;
+                if (rotate180 && !((w & 1u) && x == w / 2)) to = (size_t)(h - 1 - y) * w + (w - 1 - x);
+                uint8_t* o = rgba8 + 4 * to;
+                o[0] = x86FloatToU8(scale * s.r); o[1] = x86FloatToU8(scale * s.g); o[2] = x86FloatToU8(scale * s.b); o[3] = 255u;
+            }
+    };
+    unsigned n = threads > 0 ? (unsigned)threads : std::thread::hardware_concurrency();
+    n = std::max(1u, std::min(n, std::max(1u, h / 16u)));
+    if (n == 1) { rows(0, h); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < n; t++) th.emplace_back(rows, (uint32_t)((uint64_t)h * t / n), (uint32_t)((uint64_t)h * (t + 1) / n));
+    for (auto& t : th) t.join();
+}
+
 }  // namespace pngwriter

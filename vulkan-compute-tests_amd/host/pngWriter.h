@@ -19,6 +19,13 @@ inline uint8_t x86FloatToU8(float v) {
 }
 
 namespace pngwriter {
+// getRenderedImage's loop (mandelbrotApp.h:159-166, pathtracerApp.h:212-219) over row stripes on `threads` host threads (0 = all):
+// out[4 i + c] = static_cast<uint8_t>(scale * vec4[i][c]) with the reference binary's x86-64 semantics (x86FloatToU8), alpha 255.
+// rotate180 = the path tracer's swap loop (pathtracerApp.h:236-243) applied while writing: every pixel changes places with its point
+// reflection, except — for an odd width — the middle column, which that loop (`x < resx / 2`) never touches.  Same bytes as the
+// reference's serial loops.  `rgba8` receives w * h * 4 bytes.
+void convertStorage(const float* vec4, uint8_t* rgba8, uint32_t w, uint32_t h, float scale, bool rotate180, int threads = 0);
+
 // Returns an empty string on success, else an error description.  The image is cut into row stripes that are
 // filtered and deflated by `threads` workers in parallel (0 = all hardware threads, 1 = serial) and concatenated
 // into one valid zlib stream (sync-flushed raw-deflate pieces + combined Adler-32): at 7680x5120 the
