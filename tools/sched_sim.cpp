@@ -349,6 +349,143 @@ void sim_two_paths(const std::vector<std::vector<std::vector<uint8_t>>>& tile, i
     }
 }
 
+
+// "sphere service" (the one scheme that moves path state BETWEEN WAVES of a block, CHANGELOG round-3 §9.3): a block = NW wall waves,
+// each a sample pool as built but bouncing off walls only, + ONE service wave that owns no pixels.  A wall-wave lane whose path's next
+// hit is a sphere pushes the path (16 dwords) into the block's LDS queue and takes its pixel's next sample; the service wave pops up to
+// 64 queued paths and bounces them at full width (normal + mirror / glass + intersection), keeps those that hit a sphere again, and
+// returns the others to their home wave, whose free lanes take returned paths before new samples.  Every wave runs on its own SIMD at
+// the same rate: a discrete-event replay, every wave with its own clock in instruction-equivalents; the cost compared is the SUM over
+// the waves (an idle wave issues nothing).  `xfer` = what one block execution of push / pop costs (LDS traffic + bookkeeping).
+void sim_service(const std::vector<std::vector<std::vector<std::vector<uint8_t>>>>& tiles, size_t t0, int NW, int spp, int threshold,
+                 const Costs& c, double xfer, double poll, SplitStats& st) {
+    const int S = 16;
+    const long n_batches = (spp + S - 1) / S;
+    struct Wall {
+        long batch = 0, ghead[4] = {0, 0, 0, 0};
+        Path act[64];
+        std::vector<Path> returned;      // paths the service wave sent home (next hit a wall)
+        long outstanding = 0;            // paths of this wave at the service wave
+        double clock = 0;
+        bool done = false;
+    };
+    std::vector<Wall> w((size_t)NW);
+    for (auto& q : w) for (auto& p : q.act) p = Path{nullptr, 0};
+    struct Queued { Path p; int home; double ready; };
+    std::vector<Queued> queue;           // the block's sphere queue (FIFO)
+    Path sact[64]; int shome[64];
+    for (auto& p : sact) p = Path{nullptr, 0};
+    double sclock = 0;
+    auto wall_step = [&](int wi) {
+        Wall& q = w[(size_t)wi];
+        const auto& tile = tiles[t0 + (size_t)wi];
+        double cost = c.control + poll;
+        bool any_ret = false, any_take = false;
+        for (int l = 0; l < 64 && !q.returned.empty(); l++)
+            if (path_done(q.act[l])) { q.act[l] = q.returned.back(); q.returned.pop_back(); any_ret = true; }
+        int need[4] = {0, 0, 0, 0};
+        bool any_dead = false;
+        for (int l = 0; l < 64; l++) if (path_done(q.act[l])) { need[l / S]++; any_dead = true; }
+        if (any_dead) {
+            bool some_wants = false, some_full = false;
+            for (int p = 0; p < 4; p++) { const long avail = q.batch * S - q.ghead[p]; some_wants |= need[p] > avail; some_full |= avail > S; }
+            if (q.batch < n_batches && some_wants && !some_full) { q.batch++; cost += c.batch; }
+            for (int p = 0; p < 4; p++) {
+                const long avail = q.batch * S - q.ghead[p];
+                long rank = 0;
+                for (int j = 0; j < S; j++) {
+                    const int l = p * S + j;
+                    if (!path_done(q.act[l])) continue;
+                    if (rank < avail) {
+                        const long e = q.ghead[p] + rank;
+                        if (e < spp) { q.act[l] = Path{&tile[(size_t)p][(size_t)e], 0}; st.samples++; any_take = true; }
+                    }
+                    rank++;
+                }
+                q.ghead[p] += std::min<long>(need[p], avail);
+            }
+        }
+        if (any_take) cost += c.take;
+        if (any_ret) cost += xfer;
+        // paths whose (next) hit is a sphere go to the service wave
+        bool any_push = false;
+        for (int l = 0; l < 64; l++)
+            if (wants_sphere(q.act[l])) { queue.push_back(Queued{q.act[l], wi, q.clock}); q.act[l] = Path{nullptr, 0}; q.outstanding++; any_push = true; }
+        int alive = 0;
+        for (int l = 0; l < 64; l++) alive += !path_done(q.act[l]);
+        bool drained = q.batch >= n_batches;
+        for (int p = 0; p < 4; p++) drained &= q.ghead[p] == q.batch * S;
+        if (!alive && drained && !q.outstanding && q.returned.empty()) { q.done = true; q.clock += cost; st.cost += cost; return; }
+        if (alive) {
+            bool any_rr = false;
+            int served = 0;
+            for (int l = 0; l < 64; l++)
+                if (!path_done(q.act[l])) { any_rr |= q.act[l].pos >= 5; q.act[l].pos++; served++; }
+            cost += c.prologue + c.diffuse + c.wall_bounce + c.intersect + c.roots + c.rand + (any_rr ? c.roulette : 0.0);
+            st.iters++; st.lane_work += served;
+            for (int l = 0; l < 64; l++)   // the next hit is known at the end of the bounce: push at once
+                if (wants_sphere(q.act[l])) { queue.push_back(Queued{q.act[l], wi, q.clock + cost}); q.act[l] = Path{nullptr, 0}; q.outstanding++; any_push = true; }
+        } else {
+            cost += 40.0;   // nothing to bounce: waiting for the service wave (a short sleep; counted)
+            st.stalled++;
+        }
+        if (any_push) cost += xfer;
+        q.clock += cost; st.cost += cost;
+    };
+    auto service_step = [&]() -> bool {   // returns false when there is nothing it could do yet
+        int occupied = 0;
+        for (int l = 0; l < 64; l++) occupied += !path_done(sact[l]);
+        bool any_pop = false;
+        size_t k = 0;
+        for (int l = 0; l < 64 && k < queue.size(); l++)
+            if (path_done(sact[l])) {
+                while (k < queue.size() && queue[k].ready > sclock) k++;
+                if (k >= queue.size()) break;
+                sact[l] = queue[k].p; shome[l] = queue[k].home; queue.erase(queue.begin() + (long)k); occupied++; any_pop = true;
+            }
+        bool walls_waiting = true;
+        for (auto& q : w) if (!q.done) { int a = 0; for (int l = 0; l < 64; l++) a += !path_done(q.act[l]); if (a || q.batch < n_batches) walls_waiting = false; }
+        if (!occupied) return false;
+        if (occupied < threshold && !walls_waiting) { if (any_pop) { sclock += xfer; st.cost += xfer; } return false; }
+        double cost = c.control + poll + (any_pop ? xfer : 0.0) + c.prologue + c.normal + c.intersect + c.roots + c.rand;
+        bool any_spec = false, any_diffuse = false, any_rr = false, any_ret = false;
+        int served = 0;
+        for (int l = 0; l < 64; l++)
+            if (!path_done(sact[l])) {
+                const int mat = (*sact[l].ev)[sact[l].pos] & 3;
+                any_spec |= mat != 1; any_diffuse |= mat == 1; any_rr |= sact[l].pos >= 5;
+                sact[l].pos++; served++;
+                if (!wants_sphere(sact[l])) {    // a wall next, or the path has ended (its radiance goes home with it)
+                    Wall& h = w[(size_t)shome[l]];
+                    if (!path_done(sact[l])) h.returned.push_back(sact[l]);
+                    h.outstanding--;
+                    sact[l] = Path{nullptr, 0};
+                    any_ret = true;
+                }
+            }
+        if (any_spec) cost += c.specular;
+        if (any_diffuse) cost += c.diffuse + c.general_bounce;
+        if (any_rr) cost += c.roulette;
+        if (any_ret) cost += xfer;
+        st.phases++; st.lane_work += served;
+        sclock += cost; st.cost += cost;
+        return true;
+    };
+    for (long guard = 0; guard < 50000000; guard++) {
+        // the wave with the smallest clock runs next
+        int pick = -1;
+        double best = 1e300;
+        for (int i = 0; i < NW; i++) if (!w[(size_t)i].done && w[(size_t)i].clock < best) { best = w[(size_t)i].clock; pick = i; }
+        bool all_done = pick < 0;
+        if (all_done) break;
+        if (sclock <= best) {
+            if (!service_step()) sclock = best + 1e-9;   // nothing to do yet: sleep until the next wall wave has moved
+        } else {
+            wall_step(pick);
+        }
+    }
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -456,6 +593,21 @@ int main(int argc, char** argv) {
                        100.0 * (sp.cost / sp.samples / (base.cost / base.samples) - 1.0), sp.iters * 64.0 / sp.samples, sp.phases * 64.0 / sp.samples,
                        sp.lane_work / (sp.iters + sp.phases), sp.stalled / (sp.iters + sp.phases));
             }
+    }
+    {
+        SplitStats base;
+        for (auto& sq : ev) for (auto& tile : sq) sim_cost(tile, spp, false, 0, costs, base);
+        printf("\n  sphere service: a block = NW wall waves + 1 service wave (paths handed over through an LDS queue)\n");
+        for (int NW : {3, 7})
+            for (double xfer : {14.0, 30.0})
+                for (int T : {16, 32, 48}) {
+                    SplitStats sp;
+                    for (auto& sq : ev) for (size_t t0 = 0; t0 + (size_t)NW <= sq.size(); t0 += (size_t)NW) sim_service(sq, t0, NW, spp, T, costs, xfer, 6.0, sp);
+                    printf("  %d wall waves, transfer %2.0f, service at %2d lanes: %8.2f per sample (%+6.2f %%): %.1f wall iterations + %.1f service iterations per 64 samples, "
+                           "%.2f lanes per bounce block, %.2f waiting wall iterations\n", NW, xfer, T, sp.cost / sp.samples,
+                           100.0 * (sp.cost / sp.samples / (base.cost / base.samples) - 1.0), sp.iters * 64.0 / sp.samples, sp.phases * 64.0 / sp.samples,
+                           sp.lane_work / (sp.iters + sp.phases), sp.stalled * 64.0 / sp.samples);
+                }
     }
     return 0;
 }
