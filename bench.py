@@ -187,7 +187,11 @@ def end_to_end(cfg_names=("K2", "K4"), math="fast", probe=None):
             entry = {"image": [cfg["W"], cfg["H"]]}
             for route in ("host_buffer", "rgba8"):
                 png = os.path.join(tmp, f"{name}_{route}.png")
-                p = subprocess.run(app_command(name, route, png, math), capture_output=True, text=True, timeout=600)
+                try:
+                    p = subprocess.run(app_command(name, route, png, math), capture_output=True, text=True, timeout=600)
+                except (OSError, subprocess.SubprocessError) as e:     # the app is not built / did not finish: say so, keep the line
+                    entry[route] = {"error": repr(e)[-300:]}
+                    continue
                 line = [ln for ln in p.stdout.splitlines() if ln.startswith('{"timing_ms"')]
                 if p.returncode != 0 or not line:
                     entry[route] = {"error": (p.stdout + p.stderr)[-300:]}
