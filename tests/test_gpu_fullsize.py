@@ -87,3 +87,19 @@ def test_k3_sample_range_at_4096_spp(ctx, B, O):
     # the same rows addressed as rank 1's interleaved tile, cut down to this one block
     p = B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_STRICT, row_begin=r0, row_end=r0 + blk, row_block=blk, row_stride=n * blk)
     assert np.array_equal(bits(ctx.pathtrace(p)), bits(ref))
+
+
+def test_reference_lofi_run_bit_exact(ctx, B, O):
+    """The reference's second documented workload, `make lofi-run` (Makefile:27-28: `pocketpt 100 400` -> 600 x 400, 100 spp): the strict
+    storage buffer equals the oracle's bit for bit (sample-pool kernel; 100 = 6 x 16 + 4 samples: a ragged last batch), and the careful
+    tier asked for on the same workload stays within the fast tolerance scaled to 100 spp (a forked sample weighs 5 x what it does at 500)."""
+    W, H, spp = 600, 400, 100
+    ref = O.pathtrace(W, H, spp, math_mode=O.MATH_MC)
+    out = ctx.pathtrace(B.pathtrace_params(W, H, spp))
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+    libm = O.pathtrace(W, H, spp, math_mode=O.MATH_LIBM)[..., :3].astype(np.float64)
+    for mode, bound in ((B.PT_MATH_FAST, 20.0), (B.PT_MATH_FAST_CAREFUL, 20.0)):
+        d = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=mode))[..., :3].astype(np.float64) - libm
+        rmse, p999 = float(np.sqrt((d ** 2).mean())), float(np.percentile(np.sqrt((d ** 2).sum(-1)), 99.9))
+        print(f"lofi 600x400x100, math mode {mode}: rmse {rmse:.4f}  p99.9 L2 {p999:.3f}  mean {d.mean():+.5f}")
+        assert np.isfinite(d).all() and rmse <= 2.5 and p999 <= bound and abs(d.mean()) < 0.05
