@@ -55,7 +55,8 @@ CONFIGS = {
     "K4":   dict(kind="mandel", W=7680, H=5120, M=50000, ds=True, scaling="strong"),
 }
 WORKLOAD_ALIAS = {"pathtrace": "K2", "mandelbrot": "K1", "mandelbrot_ds": "K1ds"}
-PROFILE_TAG = {"K2": {"fast": "pt_fast", "strict": "pt_strict"}, "K1": "mandel", "K1ds": "mandel_ds", "K4": "k4"}
+PROFILE_TAG = {"K2": {"fast": "pt_fast", "strict": "pt_strict"}, "K1": "mandel", "K1ds": "mandel_ds", "K4": "k4",
+               "K3": {"fast": "k3", "strict": "k3_strict"}}
 
 
 PROFILE_ROUNDS = ("r05", "r04", "r03", "r02", "r01d", "r01c")

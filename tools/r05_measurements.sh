@@ -51,6 +51,8 @@ fuzz)       # randomised campaigns on the final build: strict parity, fast scene
 threshold)  # is "careful from five spheres on" safe?  the FAST tier on eight random boxes with 4 and eight with 3 spheres (any materials, all-specular ones too) -> profiles/r05_fast_tier_4_spheres.txt
   timeout -k 10 1100 python tools/fork_census.py --modes tier1 --scenes "4:1:201,4:1:202,4:1:203,4:2:204,4:1:205:spec,4:1:206:spec,4:1:207:spec,4:2:208:spec,3:1:211,3:1:212,3:1:213:spec,3:1:214:spec,4:1:215,4:1:216,4:1:217:spec,4:1:218:spec" \
      $L/libmc_compute.so > $out/r05_fast_tier_4_spheres.txt 2>&1 || exit 1 ;;
+profile3)   # K3's launch (3840 x 2560 x 4096, 2 s) under the counters too: its own clock and instruction mix
+  bash tools/profile_gpu.sh r05_k3 --config K3 --steps 1 --warmup 1 > $out/r05_profile_k3.log 2>&1 && python tools/summarize_prof.py r05_k3 $out/r05_k3 > /dev/null ;;
 tests)
   timeout -k 10 900 python -m pytest tests -m gpu -x -q > $out/r05_gputest.log 2>&1; rc=$?; tail -5 $out/r05_gputest.log; [ $rc -eq 0 ] || exit $rc ;;
 *) echo "usage: $0 <section> ..."; exit 2 ;;
