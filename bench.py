@@ -72,7 +72,9 @@ def profiled_summary(cfg_name, args, n):
         return None, None
     tag = PROFILE_TAG[cfg_name]
     if isinstance(tag, dict):
-        tag = tag[args.math]
+        tag = tag.get(args.math)
+        if tag is None:
+            return None, None
     family = "pt" if CONFIGS[cfg_name]["kind"] == "pt" else "mandel"
     for rnd in PROFILE_ROUNDS:
         path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}_pmc_summary.json")
@@ -240,9 +242,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 2; 1 for K3)")
     ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="BASELINE configuration (default K2)")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOAD_ALIAS), help="round-1 spelling of --config")
-    ap.add_argument("--math", default="fast", choices=["fast", "strict"],
+    ap.add_argument("--math", default="fast", choices=["fast", "careful", "strict"],
                     help="path tracer math mode: fast = gfx950 hardware transcendentals + contraction (toleranced parity, "
-                         "tests/test_gpu_fullsize.py pins it at K2), strict = IEEE + mc math (bit-identical to the oracle)")
+                         "tests/test_gpu_fullsize.py pins it at K2), careful = the fast mode's second tier asked for explicitly (no "
+                         "contraction, division / sqrt / rsq rounded as the reference rounds them; the host selects it by itself from "
+                         "five spheres on), strict = IEEE + mc math (bit-identical to the oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the end_to_end block (the standalone apps timed as child processes)")
@@ -359,7 +363,7 @@ def main():
     H = (args.height or cfg["H"]) * (n if weak else 1)
     if is_pt:
         spp = args.spp or cfg["spp"]
-        math_mode = B.PT_MATH_FAST if args.math == "fast" else B.PT_MATH_STRICT
+        math_mode = {"fast": B.PT_MATH_FAST, "careful": B.PT_MATH_FAST_CAREFUL, "strict": B.PT_MATH_STRICT}[args.math]
         pt_flags = int(os.environ.get("MC_PT_FLAGS", "0"), 0)    # experiments only (mc_pathtrace_params.flags)
         p = S.shard(B.pathtrace_params(W, H, spp, math_mode=math_mode, flags=pt_flags), rank, n)
         units_per_step = W * H * spp                         # samples
@@ -530,7 +534,10 @@ def main():
         if prof_entries and len(prof_entries) == 1:
             prof_ghz = next(iter(prof_entries.values())).get("derived", {}).get("kernel_clock_ghz")
         contracted = is_pt and args.math == "fast"
-        if is_pt and args.math == "fast":
+        if is_pt and args.math == "careful":
+            note = ("the careful tier of fast math: no contraction, division / sqrt / rsq rounded as the reference rounds them, identities "
+                    "of exact arithmetic not executed where they are free of side effects (toleranced parity, p99.9 0.44 at K2)")
+        elif is_pt and args.math == "fast":
             note = ("fast math: hardware transcendentals, a*b+c contraction, identities of exact arithmetic not executed (toleranced "
                     "parity); `achieved` counts the REFERENCE's arithmetic per sample, `executed` what the ALUs did; the strict "
                     "kernel, reported beside it, forbids all three")
