@@ -129,6 +129,25 @@ def test_error_strings_and_argument_validation_without_gpu(B):
             B.Context(0)
 
 
+def test_round5_entry_points_without_gpu(B):
+    """mc_build_id names the sources each kernel family was built from (16 hex digits each; the same ids a checkout anywhere else
+    computes: the Makefile leaves the -I paths out of the hashed flags); mc_host_alloc / mc_host_free / mc_context_last_timing validate
+    their arguments, and without a device the allocation fails loudly with a NULL pointer — never a pageable stand-in."""
+    import re
+    L = B.lib()
+    assert re.fullmatch(r"pt=[0-9a-f]{16} mandel=[0-9a-f]{16} lib=[0-9a-f]{16}", L.mc_build_id().decode())
+    assert set(B.build_id()) == {"pt", "mandel", "lib"}
+    assert L.mc_host_alloc(0, C.byref(C.c_void_p())) == 1 and L.mc_host_alloc(16, None) == 1     # MC_ERR_INVALID_ARGUMENT
+    assert L.mc_host_free(None) == 0
+    assert L.mc_context_last_timing(None, None, None) == 1
+    n = C.c_int(0)
+    if not (L.mc_device_count(C.byref(n)) == 0 and n.value > 0):
+        p = C.c_void_p(1)
+        assert L.mc_host_alloc(4096, C.byref(p)) != 0 and not p.value
+        with pytest.raises(B.McError):
+            B.HostBuffer((4, 4, 4))
+
+
 # ---- host helpers -------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def hostutil(B):
