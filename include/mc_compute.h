@@ -133,7 +133,7 @@ enum {
                            /* mc_pathtrace_select_kernel reports which (mc_pathtrace_kernel_info.math_mode).                         */
     MC_PT_MATH_FAST_CAREFUL = 2 /* the fast mode's careful tier on request: the same kernels and shortcuts, division / sqrt / 1/sqrt */
                            /* rounded as the reference rounds them and no contraction — a sample differs from the reference's by far  */
-                           /* fewer roundings and takes another path correspondingly less often; 1.2 - 1.3 x the fast tier's time     */
+                           /* fewer roundings and takes another path correspondingly less often; 1.14 - 1.43 x the fast tier's time  */
 };
 
 /* mc_pathtrace_params.flags: MC_PT_PRECISION(x) below (bits 16-19) is the one field a binding sets.  Bits 0-15 belong to this
