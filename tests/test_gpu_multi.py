@@ -126,6 +126,21 @@ def test_bench_two_gpus_rccl_verify(extra):
     assert d["config"]["exchange_async"] is True      # the overlapped exchange ran — not its synchronous fallback
 
 
+@pytest.mark.skipif("n_devices() < 2", reason="needs two GPUs")
+def test_bench_two_gpus_rccl_plain_command():
+    """The driver's plain command shape on real RCCL: `python bench.py --gpus 2 ...` with no launcher around it — bench.py starts one
+    rank per GPU itself (round 5) — asynchronous exchange required, gathered image verified against the single-GPU render."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--verify", "--spp", "16"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(env, MC_BENCH_REQUIRE_ASYNC="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    c = json.loads(lines[0])["config"]
+    assert c["backend"] == "nccl" and c["world_size"] == 2 and [x["world_size_seen"] for x in c["ranks"]] == [2, 2]
+    assert c["verified_equal_to_single_gpu"] is True and c["exchange_async"] is True
+
+
 def test_asynchronous_exchange_ordering_with_a_stub_collective(ctx, B, monkeypatch):
     """the asynchronous RCCL branch of sharding.Exchange — dist.gather(async_op=True), Work.wait() under the side
     stream, re-assembly on the side stream, two buffer sets reused through events — has never run on hardware with N > 1 (RCCL refuses
