@@ -1,6 +1,6 @@
 // Device math for the path tracer, in two flavours selected at compile time by `Fast`:
 //
-//  strict (Fast = false): every operation is one IEEE-754 fp32 operation (correctly rounded +,-,*,/,
+//  strict (Fast = 0): every operation is one IEEE-754 fp32 operation (correctly rounded +,-,*,/,
 //     sqrt, fma) in a FIXED order, so results are bit-identical to a CPU evaluating the same sequence
 //     (DESIGN.md §"mc math").  GLSL leaves sin/cos/pow/inversesqrt precision implementation-defined
 //     (SURVEY.md H5); these algorithms are this build's canonical choice for them:

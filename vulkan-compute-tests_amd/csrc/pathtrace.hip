@@ -136,8 +136,9 @@ static bool spheres_disjoint(const float* spheres, uint32_t n_spheres) {
 //   * j of glass: never (next-event estimation does not pass glass, :420; the light is seen through refraction only), two lights: never.
 constexpr double kLightGapMargin = 1.5, kMirrorMargin = 0.25;
 // Spheres from which an MC_PT_MATH_FAST request is rendered by the careful tier.  Measured on the test suite's boxes (300 x 200 x 500,
-// profiles/r05_fork_census_careful.txt; bound 4): the fast tier's 99.9-percentile reads 1.5 / 1.9 with four spheres, 3.2 with five,
-// 4.4 - 4.5 with six and seven, 5.2 - 5.6 with eight; the careful tier 1.3 with five, at most 3.0 with eight.
+// bound 4; profiles/r05_fast_tiers.txt, r05_fast_tier_4_spheres.txt): the fast tier's 99.9-percentile reads 1.1 - 3.0 on sixteen random
+// boxes with three and four spheres, 3.2 with five, 4.4 - 4.5 with six and seven, 5.2 - 5.6 with eight (the generic kernels: 5.4 with
+// twelve, 8.0 with forty); the careful tier 0.65 with five, at most 1.14 with eight (generic: 0.84 / 1.81).
 constexpr uint32_t kCarefulSpheres = 5;
 static bool light_nearly_enclosed_scan(const float* spheres, uint32_t n_spheres) {
     // the emissive spheres first (one pass; almost every scene has a handful), then each of them against the others

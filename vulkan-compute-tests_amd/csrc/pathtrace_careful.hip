@@ -1,7 +1,9 @@
 // Instantiates the CAREFUL tier of the MC_PT_MATH_FAST path tracer kernels (Fast = 2, csrc/mc_math.h): every kernel family of
-// pathtrace_fast.hip with the same fast-math identities, but compiled WITHOUT contraction (this translation unit is built under the
-// command line's -ffp-contract=off, like the strict one) and with division, square root and reciprocal square root rounded as the
-// reference rounds them (the strict mode's short forms, unguarded).
+// pathtrace_fast.hip, compiled WITHOUT contraction (this translation unit is built under the command line's -ffp-contract=off, like the
+// strict one), with division, square root and reciprocal square root rounded as the reference rounds them (the strict mode's short
+// forms, unguarded), the sphere discriminant in the reference's order and the sampled / refracted directions re-normalised; the
+// fast-math identities that are free of side effects stay (wall bounce as a permutation, one division for the slab tests, closed box,
+// shadow rays by squares, hardware sin / cos / exp / log).
 //
 // Why a second tier: a fast-math sample differs from the reference's by a rounding in almost every operation, and wherever a path
 // runs through specular spheres such a difference is amplified bounce by bounce until a discrete decision (which object, shadowed or
@@ -9,8 +11,10 @@
 // the fast tier keeps the stated tolerance (RMSE 0.5 / 99.9-percentile L2 4 at 500 spp) with margin up to four spheres, reaches the
 // bound at five and exceeds it from six on (p99.9 4.4 .. 5.6).  The census (tools/fork_census.py, profiles/r05_fork_census*.txt) shows
 // what carries the forks: contraction and the hardware seeds' last bit, in equal parts — not any one shortcut.  With both removed the
-// same scenes read 1.9 .. 3.0 at 1.18 .. 1.30 of the fast tier's time (the strict kernels: 2.4 x).  The host selects this tier for an
-// MC_PT_MATH_FAST request on a scene with five or more spheres (csrc/pathtrace.hip), and for an explicit MC_PT_MATH_FAST_CAREFUL one.
+// same scenes read 1.9 .. 3.0; with the two identities whose forks are one-sided (tools/fork_bias.py) in the reference's form as well,
+// 0.65 .. 1.14 at 1.14 .. 1.43 of the fast tier's time (profiles/r05_fast_tiers.txt; the strict kernels: 2.35 x).  The host selects this
+// tier for an MC_PT_MATH_FAST request on a scene with five or more spheres (csrc/pathtrace.hip), and for an explicit
+// MC_PT_MATH_FAST_CAREFUL one.
 #include "pathtrace_kernel.h"
 #include "pathtrace_pool.h"
 

@@ -28,8 +28,8 @@
 namespace mc {
 namespace pt {
 int launch_fast(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s) {
-    if (variant == 4) return launch_pool<true>(a, S, tile_rows, s);
-    return launch_impl<true>(a, variant, S, prec, tile_rows, s);
+    if (variant == 4) return launch_pool<1>(a, S, tile_rows, s);
+    return launch_impl<1>(a, variant, S, prec, tile_rows, s);
 }
 }  // namespace pt
 }  // namespace mc

@@ -1,5 +1,5 @@
-// The sample-pool path tracer kernels for gfx950 — closed-box scenes (SceneArgs::box_ok); fast math (included by pathtrace_fast.hip)
-// and strict math (pathtrace_strict.hip).
+// The sample-pool path tracer kernels for gfx950 — closed-box scenes (SceneArgs::box_ok); fast math (included by pathtrace_fast.hip),
+// its careful tier (pathtrace_careful.hip; `Fast` is the math tier: 0 strict, 1 fast, 2 careful) and strict math (pathtrace_strict.hip).
 //
 // Why: the round-synchronous kernels (pathtrace_kernel.h) step all 64 lanes of a wave through the depths of ONE sample each;
 // Russian roulette (pathTracer.comp:395-397) thins the wave from depth 6 on and the round still costs its longest path, so the
@@ -18,7 +18,7 @@
 // gfx950 executes an LDS float atomic at ~2 cycles per LANE — 131 LDS cycles per wave instruction, conflict or not — and the
 // kernel became LDS-bound: 33.6 ms.  profiles/r03_pool_v1_lds_atomics_pmc.txt.)
 //
-// STRICT variant (Fast = false; bit-identical to the oracle like every strict kernel): the per-pixel sum must be the reference's —
+// STRICT variant (Fast = 0; bit-identical to the oracle like every strict kernel): the per-pixel sum must be the reference's —
 // samples added in sample order (:451-:452).  A lane therefore keeps a per-PATH accrad, writes accrad / spp into its sample's slot
 // of a result ring in LDS (three batches per pixel for the reference scene, four beyond three spheres) when the path ends, and the pixel's 16 lanes add a batch's 16 results in sample
 // order — the fold of the round-synchronous kernels, fed from LDS — once every sample of the batch has ended (oldest live sample

@@ -6,8 +6,8 @@
 namespace mc {
 namespace pt {
 int launch_strict(const PTArgs& a, int variant, int S, int prec, uint32_t tile_rows, hipStream_t s) {
-    if (variant == 4) return launch_pool<false>(a, S, tile_rows, s);
-    return launch_impl<false>(a, variant, S, prec, tile_rows, s);
+    if (variant == 4) return launch_pool<0>(a, S, tile_rows, s);
+    return launch_impl<0>(a, variant, S, prec, tile_rows, s);
 }
 }  // namespace pt
 }  // namespace mc
