@@ -59,7 +59,7 @@ PROFILE_TAG = {"K2": {"fast": "pt_fast", "strict": "pt_strict"}, "K1": "mandel",
                "K3": {"fast": "k3", "strict": "k3_strict"}}
 
 
-PROFILE_ROUNDS = ("r05", "r04", "r03", "r02", "r01d", "r01c")
+PROFILE_ROUNDS = ("r06", "r05", "r04", "r03", "r02", "r01d", "r01c")
 _STALE = {}      # profile file -> why it is not quoted (build id of another library)
 
 
@@ -86,6 +86,13 @@ def profiled_summary(cfg_name, args, n):
             import __graft_entry__ as entry
             mine = entry.load_package().bindings.build_id().get(family)
             theirs = (doc.get("_build") or {}).get(family)
+            taken_on = (doc.get("_build") or {}).get("library", "vulkan-compute-tests_amd/lib/libmc_compute.so")
+            shipped = os.path.normpath(taken_on).endswith(os.path.join("lib", "libmc_compute.so"))
+            if not shipped or os.environ.get("MC_LIB_PATH"):
+                # a summary of a diagnostic library (make stats / variants / exp), or a diagnostic library loaded now: never this build's
+                _STALE[cfg_name] = (f"profiles/{os.path.basename(path)} was taken on {taken_on}" +
+                                    (f", the loaded library is {os.environ['MC_LIB_PATH']}" if os.environ.get("MC_LIB_PATH") else "") + ": not quoted")
+                return None, None
             if theirs != mine:
                 _STALE[cfg_name] = (f"profiles/{os.path.basename(path)} was taken on build {family}={theirs or 'unstamped'}, the loaded library "
                                     f"is {family}={mine}: not quoted")
@@ -256,7 +263,16 @@ def parse():
     ap.add_argument("--verify", action="store_true",
                     help="after the timed region, rank 0 re-renders the whole image on its own GPU and checks that the "
                          "gathered N-rank image is bit-identical (multi-GPU == single-GPU invariant, SURVEY §8e)")
+    ap.add_argument("--exchange", default=None, choices=["f32", "rgba8"],
+                    help="path tracer, N > 1: what the ranks send to rank 0 — f32: the fp32 vec4 tiles (16 B/pixel, the storage-buffer contract; "
+                         "default for K2), rgba8: tiles converted by their owners, 4 B/pixel (SURVEY 8(f)1; default for K3)")
+    ap.add_argument("--no-multi", action="store_true",
+                    help="N > 1: skip the `multi` block (BASELINE's 8-GPU configurations K3 and K4 after the headline)")
+    ap.add_argument("--allow-sync-exchange", action="store_true",
+                    help="N > 1 on RCCL: accept a run whose asynchronous exchange fell back to the synchronous path (default: exit 3)")
     a = ap.parse_args()
+    # the `multi` block: N > 1 from the plain command — the default headline with nothing overridden
+    a.multi = [] if (a.no_multi or a.config or a.workload or a.spp or a.width or a.height or a.gpus < 2) else ["K3", "K4"]
     if a.config and a.workload and WORKLOAD_ALIAS[a.workload] != a.config:
         ap.error("--config and --workload disagree")
     a.config = a.config or (WORKLOAD_ALIAS[a.workload] if a.workload else "K2")
@@ -312,6 +328,288 @@ def spawn_ranks(args):
     return 0
 
 
+class Job:
+    """This process's place in the job: rank, world size, device, context, launch stream (set up once by main())."""
+
+
+def measure(job, cfg_name, steps, warmup, rank, n, args, exchange="f32", verify=False, keep_image=False):
+    """Times `steps` steps of BASELINE configuration `cfg_name` on the ranks (rank, n) — n = 1 with rank 0 is a plain single-GPU
+    measurement with no collective anywhere (rank 0's own one-GPU rate inside a multi-rank job).  Returns a dict of what was
+    measured; `image` (rank 0: the assembled result, fp32 storage buffer or — exchange "rgba8" — the RGBA8 image) stays on the GPU
+    when keep_image is set.  Collective when n > 1: every rank of the job calls it with the same arguments."""
+    import numpy as np
+    torch, dist, B, S, ctx, stream = job.torch, job.dist, job.B, job.S, job.ctx, job.stream
+    ROW_BLOCK = S.ROW_BLOCK
+    cfg = CONFIGS[cfg_name]
+    is_pt = cfg["kind"] == "pt"
+    weak = cfg["scaling"] == "weak"
+    W = args.width or cfg["W"]
+    H = (args.height or cfg["H"]) * (n if weak else 1)
+    m = {"cfg_name": cfg_name, "cfg": cfg, "is_pt": is_pt, "W": W, "H": H, "n": n, "rank": rank, "steps": steps, "warmup": warmup}
+    if is_pt:
+        spp = args.spp or cfg["spp"]
+        math_mode = {"fast": B.PT_MATH_FAST, "careful": B.PT_MATH_FAST_CAREFUL, "strict": B.PT_MATH_STRICT}[args.math]
+        pt_flags = int(os.environ.get("MC_PT_FLAGS", "0"), 0)    # experiments only (mc_pathtrace_params.flags)
+        p = S.shard(B.pathtrace_params(W, H, spp, math_mode=math_mode, flags=pt_flags), rank, n)
+        units_per_step = W * H * spp                         # samples
+        m.update(flops_per_unit=FLOPS_PER_SAMPLE_PT, metric="path-traced samples/s", unit="samples/s", spp=spp,
+                 workload_name=f"{cfg_name}: pathtrace {W}x{H} spp{spp} default-scene math={args.math}")
+    else:
+        M, ds = cfg["M"], cfg["ds"]
+        kw = dict(max_iter=M)
+        if ds:
+            kw.update(precision=B.PRECISION_DS, centre=K4_VIEW["centre"], scale=K4_VIEW["scale"])
+        p = S.shard(B.mandelbrot_params(W, H, **kw), rank, n)
+        units_per_step = None                                # pixel-iters: data dependent, counted after the run
+        m.update(flops_per_unit=FLOPS_PER_PIXEL_ITER_DS if ds else FLOPS_PER_PIXEL_ITER_F32, metric="Mandelbrot pixel-iters/s",
+                 unit="pixel-iters/s", workload_name=f"{cfg_name}: mandelbrot{'_ds' if ds else ''} {W}x{H} M{M}")
+    m["p"] = p
+    owns = S.owns_rows(p)                                     # False for a rank beyond the last row block (renders nothing)
+    rows_local = B.tile_rows(p)
+    rows_padded = S.padded_tile_rows(H, n) if n > 1 else rows_local
+    m.update(rows_local=rows_local, rows_padded=rows_padded)
+    # What a rank renders into, and what it sends to rank 0 (S.Exchange: receive buffers allocated once, the gather asynchronous,
+    # rank 0's re-assembly on a side stream, two buffer sets — step i's exchange overlaps step i + 1's render):
+    #   path tracer, exchange "f32": the fp32 vec4 tile (16 B/pixel; samples are never split across ranks);
+    #   path tracer, exchange "rgba8" (SURVEY 8(f)1): every rank converts its tile on its own GPU (pathtracerApp.h:212-219), 4 B/pixel
+    #   travel, rank 0 de-interleaves and applies the point reflection on bytes (:236-243) — the image saveRenderedImage would write;
+    #   Mandelbrot, N > 1: ONLY the iteration counts — uint16 for max_iter <= 65535 (2 B/pixel) — from which rank 0 rebuilds the
+    #   vec4 storage buffer through the colour table (the colour is a function of the count alone); N = 1: vec4 + counts.
+    narrow = (not is_pt) and n > 1 and p.max_iter <= 65535
+    rgba8 = is_pt and n > 1 and exchange == "rgba8"
+    m.update(narrow=narrow, rgba8=rgba8)
+    f32_tile = None
+    if rgba8:
+        f32_tile = torch.zeros((rows_padded, W, 4), dtype=torch.float32, device="cuda")
+        ex = S.Exchange(rank, n, (rows_padded, W, 4), torch.uint8, "cuda")
+    elif is_pt or n == 1:
+        ex = S.Exchange(rank, n, (rows_padded, W, 4), torch.float32, "cuda")
+    elif narrow:
+        p.flags |= B.MANDEL_ITERS_U16
+        ex = S.Exchange(rank, n, (rows_padded, W, 2), torch.uint8, "cuda")
+    else:
+        ex = S.Exchange(rank, n, (rows_padded, W), torch.int32, "cuda")
+    iters_t = torch.zeros((rows_padded, W), dtype=torch.int32, device="cuda") if (not is_pt and n == 1) else None
+    root = n > 1 and rank == 0
+    full = torch.empty((H, W, 4), dtype=torch.uint8 if rgba8 else torch.float32, device="cuda") if root else None
+    full_iters = torch.empty((H, W), dtype=torch.int32, device="cuda") if (root and not is_pt) else None
+
+    ev_k0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    ev_k1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    ev_g1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+
+    def whole(q):
+        q = copy.copy(q)
+        q.row_begin, q.row_end, q.row_block, q.row_stride = 0, H, 0, 0
+        return q
+
+    def assemble(recv, stream_handle):                        # rank 0, on the exchange's side stream
+        if rgba8:
+            ctx.assemble_rgba8_device(recv.data_ptr(), W, H, n, ROW_BLOCK, rows_padded, True, full.data_ptr(), stream=stream_handle)
+        elif is_pt:
+            S.assemble_device(ctx, recv, W, H, n, full, stream=stream_handle)
+        else:
+            S.assemble_mandelbrot_device(ctx, whole(p), recv, n, full, full_iters, stream=stream_handle)
+
+    def step(i=None, k=0):
+        tile = ex.tile(k)
+        if i is not None:
+            ev_k0[i].record()
+        if owns:
+            if rgba8:      # render, then this rank's own float -> u8 (scale 1, no rotation: tile rows are not image rows yet)
+                ctx.pathtrace_device(p, f32_tile.data_ptr(), stream=stream)
+                ctx.convert_rgba8_device(f32_tile.data_ptr(), W, rows_local, 1.0, False, tile.data_ptr(), stream=stream)
+            elif is_pt:
+                ctx.pathtrace_device(p, tile.data_ptr(), stream=stream)
+            elif n > 1:
+                ctx.mandelbrot_device(p, 0, tile.data_ptr(), stream=stream)
+            else:
+                ctx.mandelbrot_device(p, tile.data_ptr(), iters_t.data_ptr(), stream=stream)
+        if i is not None:
+            ev_k1[i].record()
+        if n > 1:
+            ex.submit(k, assemble, ev_g1[i] if i is not None else None)
+
+    def fence():
+        ex.finish()
+        if n > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(warmup):
+        step(None, w)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i, warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    if n > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_k0, ev_k1)]))
+    gather_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_k1, ev_g1)])) if n > 1 else 0.0
+    tile = ex.tiles[(warmup + steps - 1) % len(ex.tiles)]   # the last step's tile (units are counted from it)
+
+    # ---- units ------------------------------------------------------------------------------------
+    if is_pt:
+        local_units = W * rows_local * p.spp
+    else:
+        if n == 1:
+            it = iters_t[:rows_local].to(torch.int64)
+        elif narrow:
+            it = tile[:rows_local].contiguous().view(torch.int16).to(torch.int64).squeeze(-1) & 0xffff
+        else:
+            it = tile[:rows_local].to(torch.int64)
+        M = p.max_iter
+        local_units = int(torch.where(it < M, it + 1, torch.full_like(it, M)).sum().item())   # loop bodies of the REFERENCE algorithm
+        if n > 1:
+            tot = torch.tensor([local_units], dtype=torch.int64, device="cuda")
+            dist.all_reduce(tot)
+            units_per_step = int(tot.item())
+        else:
+            units_per_step = local_units
+    m.update(dt=dt, kernel_ms=kernel_ms, gather_ms=gather_ms, gather_bytes=int(ex.bytes_per_rank) if n > 1 else 0,
+             local_units=local_units, units_per_step=units_per_step, value=units_per_step * steps / dt,
+             ms_per_step=dt / steps * 1e3, tile=tile, sync_mode=bool(ex.sync_mode), fell_back=bool(getattr(ex, "fell_back", False)),
+             exchange_async=bool(n > 1 and not ex.sync_mode and job.backend == "nccl"))
+
+    # ---- per-rank evidence: who rendered what on which device, how long (gathered to rank 0) ----------------------
+    m["ranks_info"] = None
+    if n > 1:
+        mine = torch.tensor([rank, job.device_index, rows_local, local_units, kernel_ms, gather_ms, dist.get_world_size(),
+                             1.0 if m["fell_back"] else 0.0], dtype=torch.float64, device="cuda" if job.backend == "nccl" else "cpu")
+        allv = [torch.empty_like(mine) for _ in range(n)] if rank == 0 else None
+        dist.gather(mine, allv, dst=0)
+        if rank == 0:
+            m["ranks_info"] = [{"rank": int(v[0]), "device": int(v[1]), "rows": int(v[2]), "units_per_step": int(v[3]),
+                                "kernel_ms": round(float(v[4]), 4), "gather_ms": round(float(v[5]), 4),
+                                "world_size_seen": int(v[6]), **({"exchange_fell_back": True} if v[7] else {})}
+                               for v in (t.cpu() for t in allv)]
+        # one rank's fallback is everyone's business: the collective below tells every rank (exit codes must agree)
+        fb = torch.tensor([1.0 if m["fell_back"] else 0.0], dtype=torch.float64, device="cuda" if job.backend == "nccl" else "cpu")
+        dist.all_reduce(fb, op=dist.ReduceOp.MAX)
+        m["any_fell_back"] = bool(fb.item())
+
+    # ---- optional self-check: the N-rank result == rank 0's own single-GPU render, bit for bit (outside the timed region) -------
+    # exchange "rgba8": the RGBA8 images must agree byte for byte AND — so that nothing hides behind the quantisation — the ranks'
+    # fp32 tiles, gathered once more here (untimed, 16 B/pixel), must re-assemble to the single-GPU storage buffer bit for bit.
+    m["verified"] = None
+    if verify and n > 1:
+        gathered_f32 = S.gather_tiles(f32_tile, rank, n) if rgba8 else None            # collective: every rank
+        if rank == 0:
+            q = whole(p)
+            if not is_pt:
+                q.flags &= ~B.MANDEL_ITERS_U16
+            single = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+            if is_pt:
+                ctx.pathtrace_device(q, single.data_ptr(), stream=stream)
+            else:
+                ctx.mandelbrot_device(q, single.data_ptr(), 0, stream=stream)
+            torch.cuda.synchronize()
+            if rgba8:
+                single_u8 = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+                ctx.convert_rgba8_device(single.data_ptr(), W, H, 1.0, True, single_u8.data_ptr(), stream=stream)
+                again = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+                S.assemble_device(ctx, gathered_f32, W, H, n, again, stream=stream)
+                torch.cuda.synchronize()
+                ok = bool(torch.equal(single_u8, full)) and bool(torch.equal(single.view(torch.int32), again.view(torch.int32)))
+                del single_u8, again
+            else:
+                ok = bool(torch.equal(single.view(torch.int32), full.view(torch.int32)))
+            m["verified"] = ok
+            del single
+        del gathered_f32
+    m["image"] = full if (keep_image and root) else (tile if (keep_image and n == 1) else None)
+    m["image_iters"] = full_iters if (keep_image and root) else (iters_t if (keep_image and n == 1) else None)
+    m["f32_tile"] = f32_tile if keep_image else None
+    return m
+
+
+K4_PIXEL_ITERS = 41176259776      # BASELINE.md: the frozen checksum of executed loop bodies of K4 (7680 x 5120, M = 50 000, two-float)
+
+
+def multi_block(job, args):
+    """VERDICT r5 item 1 — what the driver's one command measures at N > 1 besides the (weak-scaled) K2 headline: BASELINE's two 8-GPU
+    configurations, K3 and K4, strong-scaled over the N ranks, each with
+      value                 whole-job units / max-over-ranks wall time of the timed steps (the headline's own method);
+      ranks                 per rank: device, rows, kernel_ms, gather_ms, the world size it saw;
+      exchange_async        whether the exchange overlapped the next step's render (False on the rehearsal backend);
+      equal_to_single_gpu   the assembled N-rank result against rank 0's OWN whole-image render in the same job, bit for bit — K3: the
+                            RGBA8 image and the re-gathered fp32 storage buffer; K4: the storage buffer, the iteration plane and the
+                            frozen checksum of loop bodies (41 176 259 776);
+      retained_per_gpu      (value / N) / rank 0's one-GPU rate on the same configuration measured in the same job, same timing method.
+    Collective: every rank calls it.  Returns (block on rank 0 / None elsewhere, whether any rank's asynchronous exchange fell back)."""
+    torch, dist = job.torch, job.dist
+    rank, n = job.rank, job.n
+    plan = {"K3": dict(steps=3, warmup=1, single_steps=1, single_warmup=0, exchange=args.exchange or "rgba8"),
+            "K4": dict(steps=10, warmup=2, single_steps=5, single_warmup=1, exchange="f32")}
+    block = {}
+    bad = []
+    fell_back = False
+    margs = argparse.Namespace(width=None, height=None, spp=None, math=args.math)
+    for name in args.multi:
+        pl = plan[name]
+        mm = measure(job, name, pl["steps"], pl["warmup"], rank, n, margs, exchange=pl["exchange"], verify=False, keep_image=True)
+        fell_back = fell_back or bool(mm.get("any_fell_back"))
+        f32_again = job.S.gather_tiles(mm["f32_tile"], rank, n) if mm["rgba8"] else None   # (untimed; collective)
+        entry = None
+        if rank == 0:
+            single = measure(job, name, pl["single_steps"], pl["single_warmup"], 0, 1, margs, keep_image=True)   # rank 0 alone: no collective
+            W, H = mm["W"], mm["H"]
+            checks = {}
+            if mm["is_pt"]:
+                if mm["rgba8"]:
+                    u8 = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+                    job.ctx.convert_rgba8_device(single["image"].data_ptr(), W, H, 1.0, True, u8.data_ptr(), stream=job.stream)
+                    again = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+                    job.S.assemble_device(job.ctx, f32_again, W, H, n, again, stream=job.stream)
+                    torch.cuda.synchronize()
+                    checks["rgba8_image"] = bool(torch.equal(u8, mm["image"]))
+                    checks["f32_storage_buffer"] = bool(torch.equal(again.view(torch.int32), single["image"].view(torch.int32)))
+                    del u8, again
+                else:
+                    checks["f32_storage_buffer"] = bool(torch.equal(mm["image"].view(torch.int32), single["image"].view(torch.int32)))
+            else:
+                checks["f32_storage_buffer"] = bool(torch.equal(mm["image"].view(torch.int32), single["image"].view(torch.int32)))
+                checks["iteration_plane"] = bool(torch.equal(mm["image_iters"], single["image_iters"][:H]))
+                checks["pixel_iters"] = mm["units_per_step"]
+                if name == "K4":
+                    checks["pixel_iters_frozen"] = K4_PIXEL_ITERS
+                    checks["pixel_iters_match"] = mm["units_per_step"] == K4_PIXEL_ITERS == single["units_per_step"]
+            equal = all(v for k, v in checks.items() if isinstance(v, bool))
+            if not equal:
+                bad.append(name)
+            entry = {"workload": mm["workload_name"], "metric": mm["metric"], "unit": mm["unit"], "scaling": "strong",
+                     "value": mm["value"], "ms_per_step": mm["ms_per_step"], "steps": pl["steps"], "warmup": pl["warmup"],
+                     "image": [W, H], "n_gpus": n, "world_size": dist.get_world_size(), "ranks": mm["ranks_info"],
+                     "exchange": ("RGBA8 tiles converted by their owners (4 B/pixel)" if mm["rgba8"] else
+                                  "fp32 vec4 tiles (16 B/pixel)" if mm["is_pt"] else
+                                  ("uint16" if mm["narrow"] else "uint32") + " iteration counts"),
+                     "exchange_async": mm["exchange_async"], "gather_ms_rank0": round(mm["gather_ms"], 4),
+                     "gather_bytes_per_rank": mm["gather_bytes"],
+                     "single_gpu": {"value": single["value"], "ms_per_step": single["ms_per_step"], "kernel_ms": single["kernel_ms"],
+                                    "steps": pl["single_steps"], "device": job.device_index,
+                                    "note": "rank 0 alone on its GPU, the whole image, same job, same timing method; the other ranks idle"},
+                     "retained_per_gpu": (mm["value"] / n) / single["value"],
+                     "equal_to_single_gpu": equal, "checks": checks}
+            del single
+        del mm, f32_again
+        torch.cuda.empty_cache()
+        dist.barrier()            # the other ranks wait here while rank 0 renders alone
+        if rank == 0:
+            block[name] = entry
+    if rank == 0:
+        block["note"] = ("BASELINE's 8-GPU configurations from the plain command: strong scaling over the job's ranks, interleaved 8-row "
+                         "blocks; retained_per_gpu = (value / N) / single_gpu.value; target >= 0.9 at N = 8 (north_star)" +
+                         ("; REHEARSAL backend (ranks share GPUs, gather staged through the host): timings are not a measurement"
+                          if job.backend != "nccl" else ""))
+        block["failed_equality"] = bad
+        return block, fell_back
+    return None, fell_back
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -353,157 +651,27 @@ def main():
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     assert stream != 0
+    job = Job()
+    job.torch, job.dist, job.B, job.S, job.ctx, job.stream = torch, dist, B, S, ctx, stream
+    job.rank, job.n, job.backend, job.device_index = rank, n, backend, device_index
 
-    # ---- workload ---------------------------------------------------------------------------------
+    # ---- the headline workload ---------------------------------------------------------------------
     cfg_name = args.config
     cfg = CONFIGS[cfg_name]
     is_pt = cfg["kind"] == "pt"
-    weak = cfg["scaling"] == "weak"
-    W = args.width or cfg["W"]
-    H = (args.height or cfg["H"]) * (n if weak else 1)
-    if is_pt:
-        spp = args.spp or cfg["spp"]
-        math_mode = {"fast": B.PT_MATH_FAST, "careful": B.PT_MATH_FAST_CAREFUL, "strict": B.PT_MATH_STRICT}[args.math]
-        pt_flags = int(os.environ.get("MC_PT_FLAGS", "0"), 0)    # experiments only (mc_pathtrace_params.flags)
-        p = S.shard(B.pathtrace_params(W, H, spp, math_mode=math_mode, flags=pt_flags), rank, n)
-        units_per_step = W * H * spp                         # samples
-        flops_per_unit = FLOPS_PER_SAMPLE_PT
-        metric, unit = "path-traced samples/s", "samples/s"
-        workload_name = f"{cfg_name}: pathtrace {W}x{H} spp{spp} default-scene math={args.math}"
-    else:
-        M, ds = cfg["M"], cfg["ds"]
-        kw = dict(max_iter=M)
-        if ds:
-            kw.update(precision=B.PRECISION_DS, centre=K4_VIEW["centre"], scale=K4_VIEW["scale"])
-        p = S.shard(B.mandelbrot_params(W, H, **kw), rank, n)
-        units_per_step = None                                # pixel-iters: data dependent, counted after the run
-        flops_per_unit = FLOPS_PER_PIXEL_ITER_DS if ds else FLOPS_PER_PIXEL_ITER_F32
-        metric, unit = "Mandelbrot pixel-iters/s", "pixel-iters/s"
-        workload_name = f"{cfg_name}: mandelbrot{'_ds' if ds else ''} {W}x{H} M{M}"
-
-    owns = S.owns_rows(p)                                     # False for a rank beyond the last row block (renders nothing)
-    rows_local = B.tile_rows(p)
-    rows_padded = S.padded_tile_rows(H, n) if n > 1 else rows_local
-    # What a rank renders into, and what it sends to rank 0 (S.Exchange: receive buffers allocated once, the gather asynchronous,
-    # rank 0's re-assembly on a side stream, two buffer sets — step i's exchange overlaps step i + 1's render):
-    #   path tracer: the fp32 vec4 tile (16 B/pixel; samples are never split across ranks);
-    #   Mandelbrot, N > 1: ONLY the iteration counts — uint16 for max_iter <= 65535 (2 B/pixel) — from which rank 0 rebuilds the
-    #   vec4 storage buffer through the colour table (the colour is a function of the count alone); N = 1: vec4 + counts.
-    narrow = (not is_pt) and n > 1 and p.max_iter <= 65535
-    if is_pt:
-        ex = S.Exchange(rank, n, (rows_padded, W, 4), torch.float32, "cuda")
-    elif n > 1:
-        if narrow:
-            p.flags |= B.MANDEL_ITERS_U16
-            ex = S.Exchange(rank, n, (rows_padded, W, 2), torch.uint8, "cuda")
-        else:
-            ex = S.Exchange(rank, n, (rows_padded, W), torch.int32, "cuda")
-    else:
-        ex = S.Exchange(rank, n, (rows_padded, W, 4), torch.float32, "cuda")
-    iters_t = torch.zeros((rows_padded, W), dtype=torch.int32, device="cuda") if (not is_pt and n == 1) else None
-    full = torch.empty((H, W, 4), dtype=torch.float32, device="cuda") if n > 1 and rank == 0 else None
-    full_iters = torch.empty((H, W), dtype=torch.int32, device="cuda") if (n > 1 and rank == 0 and not is_pt) else None
-
-    ev_k0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev_k1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev_g1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-
-    def assemble(recv, stream_handle):                        # rank 0, on the exchange's side stream
-        if is_pt:
-            S.assemble_device(ctx, recv, W, H, n, full, stream=stream_handle)
-        else:
-            q = copy.copy(p)
-            q.row_begin, q.row_end, q.row_block, q.row_stride = 0, H, 0, 0
-            S.assemble_mandelbrot_device(ctx, q, recv, n, full, full_iters, stream=stream_handle)
-
-    def step(i=None, k=0):
-        tile = ex.tile(k)
-        if i is not None:
-            ev_k0[i].record()
-        if owns:
-            if is_pt:
-                ctx.pathtrace_device(p, tile.data_ptr(), stream=stream)
-            elif n > 1:
-                ctx.mandelbrot_device(p, 0, tile.data_ptr(), stream=stream)
-            else:
-                ctx.mandelbrot_device(p, tile.data_ptr(), iters_t.data_ptr(), stream=stream)
-        if i is not None:
-            ev_k1[i].record()
-        if n > 1:
-            ex.submit(k, assemble, ev_g1[i] if i is not None else None)
-
-    def fence():
-        ex.finish()
-        if n > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for w in range(args.warmup):
-        step(None, w)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, args.warmup + i)
-    fence()
-    dt = time.perf_counter() - t0
-    if n > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_k0, ev_k1)]))
+    exchange = args.exchange or ("rgba8" if cfg_name == "K3" else "f32")
+    m = measure(job, cfg_name, args.steps, args.warmup, rank, n, args, exchange=exchange, verify=args.verify)
+    W, H, p = m["W"], m["H"], m["p"]
+    rows_local, narrow, rgba8 = m["rows_local"], m["narrow"], m["rgba8"]
+    dt, kernel_ms, gather_ms, gather_bytes = m["dt"], m["kernel_ms"], m["gather_ms"], m["gather_bytes"]
+    local_units, value, tile = m["local_units"], m["value"], m["tile"]
+    metric, unit, flops_per_unit, workload_name = m["metric"], m["unit"], m["flops_per_unit"], m["workload_name"]
+    ranks_info, verified = m["ranks_info"], m["verified"]
+    spp = m.get("spp")
     sclk_mhz = ctx.measure_clock() if rank == 0 else None   # the clock this box holds under VALU load (boxes differ by >10 %)
-    gather_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_k1, ev_g1)])) if n > 1 else 0.0
-    gather_bytes = int(ex.bytes_per_rank) if n > 1 else 0     # what every rank sends to rank 0 per step
-    tile = ex.tiles[(args.warmup + args.steps - 1) % len(ex.tiles)]   # the last step's tile (units are counted from it)
-
-    # ---- units ------------------------------------------------------------------------------------
-    if is_pt:
-        local_units = W * rows_local * p.spp
-    else:
-        if n == 1:
-            it = iters_t[:rows_local].to(torch.int64)
-        elif narrow:
-            it = tile[:rows_local].contiguous().view(torch.int16).to(torch.int64).squeeze(-1) & 0xffff
-        else:
-            it = tile[:rows_local].to(torch.int64)
-        M = p.max_iter
-        local_units = int(torch.where(it < M, it + 1, torch.full_like(it, M)).sum().item())   # loop bodies of the REFERENCE algorithm
-        if n > 1:
-            tot = torch.tensor([local_units], dtype=torch.int64, device="cuda")
-            dist.all_reduce(tot)
-            units_per_step = int(tot.item())
-        else:
-            units_per_step = local_units
-    value = units_per_step * args.steps / dt
-
-    # ---- per-rank evidence: who rendered what on which device, how long (gathered to rank 0) ----------------------
-    ranks_info = None
-    if n > 1:
-        mine = torch.tensor([rank, device_index, rows_local, local_units, kernel_ms, gather_ms, dist.get_world_size()],
-                            dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        allv = [torch.empty_like(mine) for _ in range(n)] if rank == 0 else None
-        dist.gather(mine, allv, dst=0)
-        if rank == 0:
-            ranks_info = [{"rank": int(v[0]), "device": int(v[1]), "rows": int(v[2]), "units_per_step": int(v[3]),
-                           "kernel_ms": round(float(v[4]), 4), "gather_ms": round(float(v[5]), 4),
-                           "world_size_seen": int(v[6])} for v in (t.cpu() for t in allv)]
-
-    # ---- optional self-check: N-rank image == single-GPU image, bit for bit (outside the timed region) ----------
-    verified = None
-    if args.verify and n > 1 and rank == 0:
-        q = copy.copy(p)
-        q.row_begin, q.row_end, q.row_block, q.row_stride = 0, H, 0, 0
-        if not is_pt:
-            q.flags &= ~B.MANDEL_ITERS_U16
-        single = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-        if is_pt:
-            ctx.pathtrace_device(q, single.data_ptr(), stream=stream)
-        else:
-            ctx.mandelbrot_device(q, single.data_ptr(), 0, stream=stream)
-        torch.cuda.synchronize()
-        verified = bool(torch.equal(single.view(torch.int32), full.view(torch.int32)))
-        if not verified:
-            sys.exit("bench.py --verify: the gathered multi-rank image differs from the single-GPU render")
+    if args.verify and n > 1 and rank == 0 and not verified:
+        sys.exit("bench.py --verify: the gathered multi-rank image differs from the single-GPU render")
+    fell_back = bool(m.get("any_fell_back"))
 
     out = None
     if rank == 0:
@@ -550,18 +718,20 @@ def main():
             note = ("pixel-iters are loop bodies of the REFERENCE algorithm (n + 1 per escaping pixel, M per interior pixel): converged "
                     "tiles leave early through exact cycle detection, so `achieved` is reference-equivalent work per second and may "
                     "exceed the issue ceiling; `executed` is the arithmetic that actually ran")
+        sync_exchange = m["sync_mode"] or backend != "nccl"
         out = {
             "metric": metric, "value": value, "unit": unit, "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_name, "baseline_config": cfg_name, "image": [W, H], "rows_per_gpu": rows_local,
                        "tiling": "whole image" if n == 1 else f"interleaved {ROW_BLOCK}-row blocks, RCCL gather to rank 0",
-                       **({"exchange": ("fp32 vec4 tiles (16 B/pixel)" if is_pt else
+                       **({"exchange": (("RGBA8 tiles converted by their owners (4 B/pixel); rank 0 de-interleaves and point-reflects the bytes"
+                                         if rgba8 else "fp32 vec4 tiles (16 B/pixel)") if is_pt else
                                         ("uint16" if narrow else "uint32") + " iteration counts; rank 0 rebuilds the vec4 buffer through the colour table") +
-                                       ("; synchronous gather on the render stream" if ex.sync_mode or backend != "nccl" else
+                                       ("; synchronous gather on the render stream" if sync_exchange else
                                         "; asynchronous gather + re-assembly on a side stream, overlapping the next step's render")}
                           if n > 1 else {}),
-                       **({"exchange_async": bool(not ex.sync_mode and backend == "nccl")} if n > 1 else {}),
+                       **({"exchange_async": m["exchange_async"], "exchange_fell_back": fell_back} if n > 1 else {}),
                        "device": dev_name, "compute_units": cus, "sclk_mhz_probe_kernel": round(sclk_mhz, 1),
                        "sclk_note": "clock under the PROBE kernel's dense FMA chain (compares boxes); the timed kernel's own clock is roofline.kernel_clock_ghz",
                        **({"unit_note": "reference-equivalent pixel-iterations (see roofline.lane_ops.note)"} if not is_pt else {}),
@@ -598,6 +768,17 @@ def main():
                                       {"achieved": achieved_tflops * 1e12, "peak": PEAK_LANE_OPS,
                                        "frac": achieved_tflops * 1e12 / PEAK_LANE_OPS, "note": note})},
         }
+    del m
+
+    # ---- BASELINE's 8-GPU configurations (K3, K4) from the plain command: N > 1, the default headline, nothing overridden ------------
+    multi_failed = []
+    if n > 1 and args.multi:
+        torch.cuda.empty_cache()
+        blk, multi_fell_back = multi_block(job, args)
+        fell_back = fell_back or multi_fell_back
+        if rank == 0:
+            out["multi"] = blk
+            multi_failed = blk["failed_equality"]
 
     # ---- secondary metric + strict-math leg: rank 0, N = 1, default headline only, outside the timed region ----------
     if rank == 0 and n == 1 and not args.no_secondary and cfg_name == "K2":
@@ -632,7 +813,9 @@ def main():
                                          "executed_frac": (k1_exec / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS) if k1_exec else None,
                                          "executed_source": k1_exec_src or _STALE.get("K1")}}
         if args.math == "fast" and not (args.width or args.height or args.spp):
-            # the same workload with MC_PT_MATH_STRICT (IEEE divide/sqrt + mc_math: bit-identical to the oracle)
+            # the same workload with MC_PT_MATH_STRICT (IEEE divide/sqrt + mc math: bit-identical to the oracle) — which is what the C
+            # ABI's default parameters, both standalone apps and a reference tree bound to this library run unless they ask for
+            # fast math (mc_pathtrace_default_params, host/main.cpp --math): `app_default` says so beside the headline
             ps = B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_STRICT)
             ctx.pathtrace_device(ps, tile.data_ptr(), stream=stream)
             torch.cuda.synchronize()
@@ -646,6 +829,13 @@ def main():
             sms = e0.elapsed_time(e1) / reps
             out["strict_math"] = {"metric": metric, "value": W * H * spp / (sms * 1e-3), "unit": unit, "kernel_ms": sms,
                                   "note": "bit-identical to the CPU oracle (tests/test_gpu_parity.py)"}
+            out["app_default"] = {"math": "strict", "kernel_ms": sms, "value": W * H * spp / (sms * 1e-3), "unit": unit,
+                                  "frac": W * H * spp * FLOPS_PER_SAMPLE_PT / (sms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                                  "headline_math": args.math, "headline_kernel_ms": kernel_ms,
+                                  "note": "what a drop-in user gets without asking: mc_pathtrace_default_params, bin/pathtracer and route B all "
+                                          "default to MC_PT_MATH_STRICT (bit-identical to the oracle); the headline is `--math fast` "
+                                          "(toleranced parity, tests/test_gpu_fullsize.py)"}
+    del tile
 
     # ---- end to end: the standalone apps as child processes, K2 and K4, both routes; rank 0, N = 1, headline only ----
     if (rank == 0 and n == 1 and cfg_name == "K2" and not args.no_end_to_end and not (args.width or args.height or args.spp)
@@ -690,8 +880,8 @@ def main():
                 return O.mandel_pixel_iters(itc, p.max_iter)
 
             t = time.perf_counter()
-            with ThreadPoolExecutor(threads) as ex:
-                tot = sum(ex.map(one_row, rows))
+            with ThreadPoolExecutor(threads) as tex:
+                tot = sum(tex.map(one_row, rows))
             cdt = time.perf_counter() - t
             out["cpu_baseline"] = {"value": tot / cdt, "unit": unit, "cores": threads, "kind": "port",
                                    "sample": f"every {stride}th row of the {W}x{H} image ({tot} pixel-iters, {cdt:.1f} s)"}
@@ -700,15 +890,29 @@ def main():
         out["cpu_baseline"]["lavapipe_probe"] = lavapipe_probe()   # all four must exist for kind "reference"; they do not here
     if rank == 0:
         print(json.dumps(out), flush=True)
-    # A run that was meant to overlap its exchange (RCCL, not MC_BENCH_SYNC_EXCHANGE) but fell back to the synchronous path has
-    # measured something else: MC_BENCH_REQUIRE_ASYNC=1 (the multi-GPU self-test) turns that into a failure.
-    if n > 1 and backend == "nccl" and os.environ.get("MC_BENCH_REQUIRE_ASYNC") == "1" and ex.sync_mode:
-        ctx.close()
-        dist.destroy_process_group()
-        sys.exit("bench.py: the asynchronous exchange fell back to the synchronous path (MC_BENCH_REQUIRE_ASYNC=1)")
+    # Refusing to degrade silently.  A job that was meant to overlap its exchange (RCCL, not the explicit
+    # MC_BENCH_SYNC_EXCHANGE=1) but fell back to the synchronous path has measured something else: the line above says so
+    # (`exchange_async`: false, `exchange_fell_back`: true) and the job EXITS NON-ZERO unless --allow-sync-exchange was given.  So does
+    # a multi block whose N-rank result differs from rank 0's single-GPU render.  Every rank takes the same exit (the flags were
+    # all-reduced), after the process group is torn down.
+    code = 0
+    if n > 1:
+        flags = torch.tensor([1.0 if fell_back else 0.0, float(len(multi_failed))], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+        if flags[0].item() and backend == "nccl" and not args.allow_sync_exchange:
+            code = 3
+            if rank == 0:
+                print("bench.py: the asynchronous exchange fell back to the synchronous path on at least one rank — the line above is "
+                      "not the overlapped measurement; exit 3 (pass --allow-sync-exchange to accept it)", file=sys.stderr, flush=True)
+        if flags[1].item():
+            code = 4
+            if rank == 0:
+                print(f"bench.py: multi-rank result differs from the single-GPU render for {multi_failed}; exit 4", file=sys.stderr, flush=True)
     ctx.close()
     if n > 1:
         dist.destroy_process_group()
+    if code:
+        sys.exit(code)
 
 
 if __name__ == "__main__":

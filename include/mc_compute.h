@@ -28,7 +28,10 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 1
+/* 2 (round 6): + mc_assemble_rgba8_device_async, mc_context_warmup_*, mc_*_render_begin / mc_render_end; since 1 (round 5 additions, un-bumped then): mc_build_id,
+ * mc_host_alloc / mc_host_free, mc_context_last_timing, math_mode 2, scene-class bit 16; the measurement flag enums moved to
+ * mc_compute_test.h.  A binder checks mc_abi_version() against the MC_ABI_VERSION it was written for. */
+#define MC_ABI_VERSION 2
 
 typedef enum mc_status {
     MC_OK = 0,
@@ -196,6 +199,32 @@ int mc_mandelbrot_render_rgba8(mc_context* ctx, const mc_mandelbrot_params* p, u
 int mc_pathtrace_render_rgba8(mc_context* ctx, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
                               const float* spheres, uint32_t n_spheres, uint8_t* out_rgba8);
 
+/* ---- cold start (no reference counterpart: vkCreateComputePipelines compiles the shader inside preRun, vulkanComputeApp.cpp:589-643,
+ *      before anything is timed; here the runtime loads a kernel family's code object on its first launch, 8 - 12 ms, and the first
+ *      full-size launch would pay for it) -----------------------------------------------------------------------------------------
+ * mc_context_warmup_*: everything the request's first launch would otherwise do once — device scratch for the whole request (and the
+ * RGBA8 image when rgba8 != 0), timing events, scene / colour / c tables, and a 16 x 8 (one-tile) launch of the kernel family the
+ * request selects, so that the code object is resident.  Blocks the CALLING thread for the load and returns with the tiny launch
+ * queued on the context's stream; results are unaffected (the scratch it touches is overwritten by the render).  An application calls
+ * it from a helper thread while it does other start-up work, and joins that thread before its next call on the context (a context
+ * is not thread-safe). */
+int mc_context_warmup_pathtrace(mc_context* ctx, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
+                                const float* spheres, uint32_t n_spheres, int rgba8);
+int mc_context_warmup_mandelbrot(mc_context* ctx, const mc_mandelbrot_params* p, int rgba8);
+
+/* Two-phase form of the blocking host-buffer calls.  The kernels write HBM; the application's host buffer is needed only by the
+ * final copy — unlike the reference, whose shader writes the mapped host-visible buffer directly and must therefore allocate it first
+ * (vulkanComputeApp.cpp:489-533 in preRun, before the dispatch of :451-466).  mc_*_render_begin launches the render (rgba8 != 0: and
+ * the conversion of mc_*_render_rgba8) and returns at once; mc_render_end copies the result — (row_end-row_begin)*width*16 bytes, or
+ * width*height*4 for rgba8 — to out_host and blocks until it is there.  out_bytes must be exactly that size.  An application can
+ * therefore allocate (pin, page in) its storage buffer WHILE the device renders.  Same results, same timing record
+ * (mc_context_last_timing), same errors as mc_mandelbrot_render(out_iters = NULL) / mc_pathtrace_render / mc_*_render_rgba8; the
+ * path tracer's form renders from sample 0 (a progressive continuation uploads the caller's accumulator: the blocking call). */
+int mc_mandelbrot_render_begin(mc_context* ctx, const mc_mandelbrot_params* p, int rgba8);
+int mc_pathtrace_render_begin(mc_context* ctx, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
+                              const float* spheres, uint32_t n_spheres, int rgba8);
+int mc_render_end(mc_context* ctx, void* out_host, size_t out_bytes);
+
 /* Host-side analysis the path tracer applies to a scene before choosing a kernel; touches no device, usable without a
  * GPU.  *out_class: bit 0 (MC_PT_SCENE_SLAB) — six axis-aligned planes in index order x,x,y,y,z,z plus one to eight spheres
  * (the reference scene, pathtracerApp.h:14-39, has three): the specialised slab kernels run; bit 1 (MC_PT_SCENE_LIGHTS_INSIDE) —
@@ -255,6 +284,14 @@ int mc_deinterleave_rows_device_async(mc_context* ctx, const void* d_tiles, uint
                                       uint32_t n_tiles, uint32_t row_block, uint32_t tile_rows_padded,
                                       uint32_t bytes_per_pixel, void* d_out, void* stream);
 
+/* Path-tracer RGBA8 exchange on the root (4 B/pixel cross xGMI): d_tiles_rgba8 holds n_tiles interleaved tiles of
+ * RGBA8 pixels, each converted by its owner with mc_convert_rgba8_device_async(rotate180 = 0), laid out as
+ * mc_deinterleave_rows_device_async expects; writes the whole image d_rgba8 (width*height*4 bytes) in storage-row order and, with
+ * rotate180 != 0, point-reflected as PathtracerApp::saveRenderedImage leaves it (pathtracerApp.h:236-243, incl. an odd width's
+ * untouched middle column) — the same bytes as mc_pathtrace_render_rgba8 of the whole image on one GPU. */
+int mc_assemble_rgba8_device_async(mc_context* ctx, const void* d_tiles_rgba8, uint32_t width, uint32_t height, uint32_t n_tiles,
+                                   uint32_t row_block, uint32_t tile_rows_padded, int rotate180, void* d_rgba8, void* stream);
+
 /* Mandelbrot exchange on the root: d_tiles holds n_tiles interleaved tiles of ITERATION COUNTS (iters_bytes = 2: uint16_t,
  * MC_MANDEL_ITERS_U16; 4: uint32_t) laid out as mc_deinterleave_rows_device_async expects; writes the whole image's storage
  * buffer d_rgba_f32 (lut[n] per pixel: exactly what the render kernel writes for that count, mandelbrot.comp:50-59) and/or its
@@ -273,7 +310,9 @@ int mc_multi_destroy(mc_multi* m);
 int mc_multi_mandelbrot_render(mc_multi* m, const mc_mandelbrot_params* p, float* out_rgba_f32, uint32_t* out_iters);
 int mc_multi_pathtrace_render(mc_multi* m, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
                               const float* spheres, uint32_t n_spheres, float* out_rgba_f32);
-/* As mc_*_render_rgba8: the assembled storage buffer is converted on device 0 and only RGBA8 leaves the GPU. */
+/* As mc_*_render_rgba8: only RGBA8 leaves the GPU.  Mandelbrot: device 0 converts the storage buffer it rebuilt from the gathered
+ * counts.  Path tracer: every device converts its own tile, the gather moves 4 B/pixel, device 0 de-interleaves and applies the
+ * point reflection on bytes (mc_assemble_rgba8_device_async). */
 int mc_multi_mandelbrot_render_rgba8(mc_multi* m, const mc_mandelbrot_params* p, uint8_t* out_rgba8);
 int mc_multi_pathtrace_render_rgba8(mc_multi* m, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
                                     const float* spheres, uint32_t n_spheres, uint8_t* out_rgba8);

@@ -148,3 +148,68 @@ def test_two_rank_rehearsal_mandelbrot_exchanges_iteration_counts():
     assert c["verified_equal_to_single_gpu"] is True and "uint16" in c["exchange"]
     assert c["gather_bytes_per_rank"] == 264 * 768 * 2      # rank 0's tile: 33 of the 65 row blocks
     assert sum(r["units_per_step"] for r in c["ranks"]) == round(d["value"] * d["ms_per_step"] * 1e-3)
+
+
+MULTI_KEYS = ("workload", "metric", "unit", "scaling", "value", "ms_per_step", "image", "n_gpus", "world_size", "ranks", "exchange",
+              "exchange_async", "gather_ms_rank0", "gather_bytes_per_rank", "single_gpu", "retained_per_gpu", "equal_to_single_gpu", "checks")
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_plain_command_carries_the_8gpu_configurations(n):
+    """the driver's ONE command — `python bench.py --gpus N`, nothing else — must measure BASELINE's two 8-GPU
+    configurations too.  After the (weak-scaled) K2 headline the line carries a `multi` block: K3 (3840 x 2560 x 4096 spp, RGBA8
+    exchange: 4 B/pixel) and K4 (7680 x 5120, M = 50 000, two-float, 16-bit counts) at FULL size, strong-scaled over the N ranks, each
+    with per-rank evidence, a bit-equality check against rank 0's own single-GPU render in the same job (K4 also against the frozen
+    checksum 41 176 259 776) and retained_per_gpu.  gloo rehearsal on the one GPU: the ranks share it, so the TIMINGS mean nothing
+    (the block says so) — the keys, the sharding, the exchange formats and the equalities are what is asserted."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], cwd=ROOT, env=dict(env, MC_BENCH_BACKEND="gloo"),
+                       capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]
+    d = json.loads(lines[0])
+    check_common(d, n, 10, 2)
+    assert d["config"]["baseline_config"] == "K2" and d["config"]["image"] == [900, 600 * n]      # nothing about the headline changes
+    assert d["config"]["gather_bytes_per_rank"] == 600 * 900 * 16 and d["config"]["exchange_fell_back"] is False
+    mb = d["multi"]
+    assert mb["failed_equality"] == [] and "REHEARSAL" in mb["note"]
+    for name, image in (("K3", [3840, 2560]), ("K4", [7680, 5120])):
+        e = mb[name]
+        assert not [k for k in MULTI_KEYS if k not in e], [k for k in MULTI_KEYS if k not in e]
+        assert e["image"] == image and e["n_gpus"] == n and e["world_size"] == n and e["scaling"] == "strong"
+        assert [r["rank"] for r in e["ranks"]] == list(range(n)) and all(r["world_size_seen"] == n for r in e["ranks"])
+        assert sum(r["rows"] for r in e["ranks"]) == image[1] and all(r["kernel_ms"] > 0 for r in e["ranks"])
+        assert e["equal_to_single_gpu"] is True and all(v for v in e["checks"].values() if isinstance(v, bool))
+        assert e["exchange_async"] is False                                      # (the rehearsal backend stages through the host)
+        assert e["single_gpu"]["value"] > 0 and abs(e["retained_per_gpu"] - e["value"] / n / e["single_gpu"]["value"]) < 1e-9
+    k3, k4 = mb["K3"], mb["K4"]
+    assert k3["gather_bytes_per_rank"] == 4 * 3840 * (2560 // n) and "RGBA8" in k3["exchange"]           # 4 B/pixel (SURVEY 8(f)1)
+    assert set(k3["checks"]) == {"rgba8_image", "f32_storage_buffer"}
+    assert abs(k3["value"] - 3840 * 2560 * 4096 / (k3["ms_per_step"] * 1e-3)) / k3["value"] < 1e-6
+    assert k4["gather_bytes_per_rank"] == 2 * 7680 * (5120 // n) and "uint16" in k4["exchange"]
+    assert k4["checks"]["pixel_iters"] == k4["checks"]["pixel_iters_frozen"] == 41176259776 and k4["checks"]["pixel_iters_match"] is True
+    assert sum(r["units_per_step"] for r in k4["ranks"]) == 41176259776
+
+
+def test_rgba8_exchange_of_the_headline_and_its_verify():
+    """--exchange rgba8 on the K2 geometry (2 ranks, gloo rehearsal) with --verify: the RGBA8 image equals the single-GPU render's,
+    and the fp32 tiles — gathered once more, untimed — re-assemble to the single-GPU storage buffer bit for bit."""
+    launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29561"]
+    d = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "16", "--exchange", "rgba8", "--verify"],
+                  env_extra={"MC_BENCH_BACKEND": "gloo"}, launcher=launcher)
+    check_common(d, 2, 2, 1)
+    c = d["config"]
+    assert c["verified_equal_to_single_gpu"] is True and "RGBA8" in c["exchange"] and c["gather_bytes_per_rank"] == 600 * 900 * 4
+    assert "multi" not in d                                                      # overridden sizes: the headline only
+
+
+def test_app_default_math_is_reported_beside_the_headline():
+    """the headline is `--math fast`; what the C ABI's defaults, bin/pathtracer and route B render without being
+    asked is strict.  The un-overridden N = 1 line says so in `app_default`, next to `strict_math`."""
+    d = run_bench(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end"])
+    a = d["app_default"]
+    assert a["math"] == "strict" and a["headline_math"] == "fast" and a["kernel_ms"] == d["strict_math"]["kernel_ms"]
+    assert a["kernel_ms"] > 1.5 * a["headline_kernel_ms"] and 0.1 < a["frac"] < d["roofline"]["frac"]
+    r = d["roofline"]
+    assert "variant=shipped" in r["build_id"]

@@ -191,3 +191,137 @@ def test_pinned_and_pageable_callers_get_identical_bytes_at_the_pinned_rate(ctx,
     with B.Context(0) as fresh:      # before the first blocking host-buffer call there is nothing to report
         with pytest.raises(B.McError):
             fresh.last_timing()
+
+
+def test_two_phase_calls_and_warmup_equal_the_blocking_calls(B, O):
+    """Round 6: mc_context_warmup_* + mc_*_render_begin / mc_render_end — what the apps use to hide the cold start
+    and the pinned allocation — return exactly what the blocking calls return: the fp32 storage buffer and the RGBA8 image, Mandelbrot
+    (fp32 and two-float) and path tracer (strict and fast), on a FRESH context whose first call is the warm-up; argument errors."""
+    L = B.lib()
+    vp, u32 = C.c_void_p, C.c_uint32
+    L.mc_context_warmup_pathtrace.argtypes = [vp, C.POINTER(B.PathtraceParams), vp, u32, vp, u32, C.c_int]
+    L.mc_context_warmup_mandelbrot.argtypes = [vp, C.POINTER(B.MandelbrotParams), C.c_int]
+    L.mc_pathtrace_render_begin.argtypes = [vp, C.POINTER(B.PathtraceParams), vp, u32, vp, u32, C.c_int]
+    L.mc_mandelbrot_render_begin.argtypes = [vp, C.POINTER(B.MandelbrotParams), C.c_int]
+    L.mc_render_end.argtypes = [vp, vp, C.c_size_t]
+    L.mc_pathtrace_render_rgba8.argtypes = [vp, C.POINTER(B.PathtraceParams), vp, u32, vp, u32, vp]
+    L.mc_mandelbrot_render_rgba8.argtypes = [vp, C.POINTER(B.MandelbrotParams), vp]
+    planes, spheres = B.default_scene()
+    pl, sp = planes.ctypes.data_as(vp), spheres.ctypes.data_as(vp)
+
+    def ptr(a):
+        return a.ctypes.data_as(vp)
+
+    with B.Context(0) as ref_ctx:
+        for mode in (B.PT_MATH_STRICT, B.PT_MATH_FAST):
+            for W, H in ((96, 64), (51, 30)):
+                q = B.pathtrace_params(W, H, 12, math_mode=mode)
+                want = ref_ctx.pathtrace(q)
+                want8 = np.empty((H, W, 4), np.uint8)
+                assert L.mc_pathtrace_render_rgba8(ref_ctx._h, C.byref(q), pl, 6, sp, 3, ptr(want8)) == 0
+                for rgba8 in (0, 1):
+                    with B.Context(0) as c:                       # fresh: the warm-up is this context's first launch
+                        assert L.mc_context_warmup_pathtrace(c._h, C.byref(q), pl, 6, sp, 3, rgba8) == 0
+                        assert L.mc_pathtrace_render_begin(c._h, C.byref(q), pl, 6, sp, 3, rgba8) == 0
+                        got = np.zeros((H, W, 4), np.uint8 if rgba8 else np.float32)
+                        assert L.mc_render_end(c._h, ptr(got), got.nbytes - 4) == 1          # wrong size: refused, still pending
+                        assert L.mc_render_end(c._h, ptr(got), got.nbytes) == 0
+                        assert L.mc_render_end(c._h, ptr(got), got.nbytes) == 1              # nothing pending any more
+                        k, cp = c.last_timing()
+                        assert k > 0 and cp > 0
+                        if rgba8:
+                            assert np.array_equal(got, want8)
+                        else:
+                            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        # a tile (interleaved rows) through the two-phase form; a continuation is refused there
+        q = B.pathtrace_params(64, 48, 6, row_begin=8, row_end=48, row_block=8, row_stride=16)
+        want = ref_ctx.pathtrace(q)
+        with B.Context(0) as c:
+            assert L.mc_pathtrace_render_begin(c._h, C.byref(q), pl, 6, sp, 3, 0) == 0
+            got = np.zeros_like(want)
+            assert L.mc_render_end(c._h, ptr(got), got.nbytes) == 0 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+            assert L.mc_pathtrace_render_begin(c._h, C.byref(q), pl, 6, sp, 3, 1) == 1       # RGBA8: whole, finished images only
+            q2 = B.pathtrace_params(64, 48, 6, sample_begin=2)
+            assert L.mc_pathtrace_render_begin(c._h, C.byref(q2), pl, 6, sp, 3, 0) == 1
+        # Mandelbrot, fp32 and two-float (the warm-up builds the REAL colour / c tables, then runs one short tile)
+        for kw in (dict(max_iter=300), dict(max_iter=700, precision=B.PRECISION_DS, centre=(-0.7436438870371587, 0.13182590420531198),
+                                            scale=(1e-6, 1e-6))):
+            p = B.mandelbrot_params(200, 121, **kw)
+            want, _ = ref_ctx.mandelbrot(p, want_iters=False)
+            want8 = np.empty((121, 200, 4), np.uint8)
+            assert L.mc_mandelbrot_render_rgba8(ref_ctx._h, C.byref(p), ptr(want8)) == 0
+            for rgba8 in (0, 1):
+                with B.Context(0) as c:
+                    assert L.mc_context_warmup_mandelbrot(c._h, C.byref(p), rgba8) == 0
+                    assert L.mc_mandelbrot_render_begin(c._h, C.byref(p), rgba8) == 0
+                    got = np.zeros((121, 200, 4), np.uint8 if rgba8 else np.float32)
+                    assert L.mc_render_end(c._h, ptr(got), got.nbytes) == 0
+                    assert np.array_equal(got, want8) if rgba8 else np.array_equal(got.view(np.uint32), want.view(np.uint32))
+                    # the blocking call on a warmed context: unchanged, iteration plane included
+                    rg, it = c.mandelbrot(p)
+                    assert np.array_equal(rg.view(np.uint32), want.view(np.uint32))
+        assert L.mc_render_end(None, ptr(want8), 4) == 1 and L.mc_context_warmup_mandelbrot(None, C.byref(p), 0) == 1
+
+
+def test_apps_overlapped_start_writes_the_same_file_as_the_serial_start(B, tmp_path):
+    """The apps start the storage buffer's allocation and the warm-up on helper threads (init()) and join them where they are
+    needed; --serial-start is the round-5 order.  Same file bytes either way, both routes, both apps; the timing line says what ran."""
+    import json
+    bindir = os.path.join(os.path.dirname(os.path.dirname(B.LIB_PATH)), "bin")
+    for app, args in (("pathtracer", ["6", "48"]), ("pathtracer", ["6", "48", "--math", "fast"]), ("pathtracer", ["6", "48", "--math", "careful"]),
+                      ("mandelbrot", ["--width", "320", "--height", "200", "--max-iter", "300"])):
+        for route in ([], ["--gpu-postprocess"]):
+            files = []
+            for start in ([], ["--serial-start"]):
+                out = tmp_path / f"{app}{len(files)}.png"
+                r = subprocess.run([os.path.join(bindir, app)] + args + route + start + ["--quiet", "--timing-json", "--out", str(out)],
+                                   capture_output=True, text=True, cwd=tmp_path)
+                assert r.returncode == 0, r.stdout + r.stderr
+                t = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"timing_ms"')][0])
+                assert t["overlap_start"] is (not start) and t["timing_ms"]["kernel"] > 0
+                if not start:
+                    assert t["timing_ms"]["warmup"] > 0 and t["timing_ms"]["alloc_thread"] > 0
+                files.append(open(out, "rb").read())
+            assert files[0] == files[1], (app, args, route)
+
+
+def test_reference_png_mode_writes_the_reference_bytes(B, O, tmp_path):
+    """VERDICT r5 item 3 / north_star "bit-identical PNG": route A with the reference's own codec.  `make REFERENCE=<checkout>`
+    (what __graft_entry__.build() does where the checkout exists) compiles the reference's lodepng.cpp WHERE IT LIES into the apps
+    behind --reference-png; this test runs wherever such a build is present (the GPU box receives the built binaries, not the
+    checkout).  bin/mandelbrot --reference-png at 256 x 256, M = 128 must be the file whose SHA-256 was frozen from the reference
+    codec over the oracle's pixels (tests/golden/mandelbrot_256_M128_lodepng.sha256, tests/golden/make_golden.py); at the reference's
+    default 2000 x 2000 and for bin/pathtracer at ITS defaults (500 spp, 900 x 600, strict) the file must equal oracle/_ref's
+    lodepng::encode of the oracle's pixels byte for byte (when oracle/_ref travelled too)."""
+    import hashlib
+    from conftest import GOLDEN
+    bindir = os.path.join(os.path.dirname(os.path.dirname(B.LIB_PATH)), "bin")
+    probe = subprocess.run([os.path.join(bindir, "mandelbrot"), "--reference-png", "--width", "8", "--height", "8", "--quiet"],
+                           capture_output=True, text=True, cwd=tmp_path)
+    if probe.returncode != 0 and "built without the reference's PNG codec" in probe.stdout:
+        pytest.skip("the apps were built without REFERENCE=<checkout> (no reference checkout where they were built)")
+    assert probe.returncode == 0, probe.stdout + probe.stderr
+    r = subprocess.run([os.path.join(bindir, "mandelbrot"), "--reference-png", "--width", "256", "--height", "256", "--quiet"],
+                       capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    golden = open(os.path.join(GOLDEN, "mandelbrot_256_M128_lodepng.sha256")).read().split()[0]
+    assert hashlib.sha256(open(tmp_path / "mandelbrot.png", "rb").read()).hexdigest() == golden
+    # the same pixels through the apps' own writer: another (valid) file, the same image
+    from PIL import Image
+    r = subprocess.run([os.path.join(bindir, "mandelbrot"), "--width", "256", "--height", "256", "--quiet", "--out", "own.png"],
+                       capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "own.png").convert("RGBA")), np.asarray(Image.open(tmp_path / "mandelbrot.png").convert("RGBA")))
+    if O.ref_lodepng() is None:
+        return
+    _, lut_u8 = O.mandel_lut(128)
+    want_m = bytes(O.ref_png_encode(np.ascontiguousarray(lut_u8[O.mandelbrot_iters(2000, 2000, 128)]), 2000, 2000))
+    ref = O.pathtrace(900, 600, 500, math_mode=O.MATH_MC)
+    want_p = bytes(O.ref_png_encode(np.ascontiguousarray(O.rotate180(O.float_to_rgba8(ref, 1.0).reshape(600, 900, 4), 900, 600)), 900, 600))
+    for extra in ([], ["--gpu-postprocess"]):
+        r = subprocess.run([os.path.join(bindir, "mandelbrot"), "--reference-png", "--quiet"] + extra, capture_output=True, text=True, cwd=tmp_path)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert open(tmp_path / "mandelbrot.png", "rb").read() == want_m
+        r = subprocess.run([os.path.join(bindir, "pathtracer"), "--reference-png", "--quiet"] + extra, capture_output=True, text=True, cwd=tmp_path)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert open(tmp_path / "pathtracer.png", "rb").read() == want_p

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("MC_LIB_PATH") or os.path.join(_HERE, "lib", "libmc_co
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mc_compute.h")
 
 MC_OK = 0
+ABI_VERSION = 2   # MC_ABI_VERSION of include/mc_compute.h this binding is written against
 PRECISION_F32, PRECISION_DS = 0, 1
 PT_MATH_STRICT, PT_MATH_FAST, PT_MATH_FAST_CAREFUL = 0, 1, 2
 MANDEL_FMA = 1
@@ -78,6 +79,12 @@ def lib():
             raise FileNotFoundError(f"{LIB_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'`")
         L = C.CDLL(LIB_PATH)
         vp, u32, i32, f32 = C.c_void_p, C.c_uint32, C.c_int, C.c_float
+        # The binding below is written against ABI_VERSION of include/mc_compute.h.  A diagnostic build loaded through MC_LIB_PATH may
+        # be older (it then lacks the entry points added since, bound conditionally below); the shipped library must match.
+        have = int(L.mc_abi_version())
+        if have != ABI_VERSION and not os.environ.get("MC_LIB_PATH"):
+            raise RuntimeError(f"{LIB_PATH} reports ABI version {have}, this binding is written against {ABI_VERSION}: rebuild "
+                               f"(python -c 'import __graft_entry__ as g; g.build()')")
         L.mc_error_string.restype = C.c_char_p
         L.mc_error_string.argtypes = [i32]
         L.mc_last_error_detail.restype = C.c_char_p
@@ -104,12 +111,16 @@ def lib():
         L.mc_pathtrace_render_device_async.argtypes = [vp, C.POINTER(PathtraceParams), vp, u32, vp, u32, vp, vp]
         L.mc_convert_rgba8_device_async.argtypes = [vp, vp, u32, u32, f32, i32, vp, vp]
         L.mc_convert_rgba8.argtypes = [vp, vp, u32, u32, f32, i32, vp]
-        if hasattr(L, "mc_build_id"):   # (a diagnostic build older than round 5, loaded through MC_LIB_PATH, lacks these four)
+        if have >= 2 or hasattr(L, "mc_build_id"):   # (ABI 1 libraries older than round 5 lack these four)
             L.mc_build_id.restype = C.c_char_p
             L.mc_build_id.argtypes = []
             L.mc_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
             L.mc_host_free.argtypes = [vp]
             L.mc_context_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        if have >= 2:   # round 6
+            L.mc_assemble_rgba8_device_async.argtypes = [vp, vp, u32, u32, u32, u32, u32, i32, vp, vp]
+            L.mc_multi_pathtrace_render_rgba8.argtypes = [vp, C.POINTER(PathtraceParams), vp, u32, vp, u32, vp]
+            L.mc_multi_mandelbrot_render_rgba8.argtypes = [vp, C.POINTER(MandelbrotParams), vp]
         L.mc_multi_create.argtypes = [i32, C.POINTER(vp)]
         L.mc_multi_destroy.argtypes = [vp]
         L.mc_multi_mandelbrot_render.argtypes = [vp, C.POINTER(MandelbrotParams), vp, vp]
@@ -260,6 +271,21 @@ class HostBuffer:
     def __exit__(self, *a):
         self.free()
 
+    def __del__(self):   # (views handed out earlier dangle once the buffer is freed: keep the HostBuffer alive while `array` is in use)
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _check_out(out, shape, what):
+    """The caller's own output array goes to the library as a bare pointer: it must be exactly the buffer the call fills."""
+    if not isinstance(out, np.ndarray) or out.dtype != np.float32 or tuple(out.shape) != tuple(shape):
+        raise ValueError(f"{what}: out must be a float32 array of shape {tuple(shape)}, got "
+                         f"{getattr(out, 'dtype', type(out))} {getattr(out, 'shape', '')}")
+    if not out.flags.c_contiguous or not out.flags.writeable:
+        raise ValueError(f"{what}: out must be C-contiguous and writeable")
+
 
 def pathtrace_scene_class(planes, spheres):
     """mc_pathtrace_scene_class: which kernel specialisations the host would select for this scene (no device needed)."""
@@ -321,6 +347,10 @@ class Context:
     # ---- host-buffer forms -------------------------------------------------------------------------
     def mandelbrot(self, p, want_rgba=True, want_iters=True, out=None):
         rows = tile_rows(p)
+        if out is not None:
+            if not want_rgba:
+                raise ValueError("Context.mandelbrot: out= is the colour buffer; it needs want_rgba=True")
+            _check_out(out, (rows, p.width, 4), "Context.mandelbrot")
         rgba = (out if out is not None else np.empty((rows, p.width, 4), np.float32)) if want_rgba else None
         iters = np.empty((rows, p.width), np.uint32) if want_iters else None
         _check(lib().mc_mandelbrot_render(self._h, C.byref(p), _ptr(rgba), _ptr(iters)), "mc_mandelbrot_render")
@@ -332,7 +362,11 @@ class Context:
         planes = np.ascontiguousarray(planes, np.float32).reshape(-1)
         spheres = np.ascontiguousarray(spheres, np.float32).reshape(-1)
         rows = tile_rows(p)
-        if out is None:   # (out: the caller's own buffer, e.g. HostBuffer.array — written in place)
+        if out is not None:   # (out: the caller's own buffer, e.g. HostBuffer.array — written in place)
+            _check_out(out, (rows, p.width, 4), "Context.pathtrace")
+            if acc is not None:   # a progressive continuation starts from the accumulator: it goes into the caller's buffer first
+                out[...] = np.asarray(acc, np.float32).reshape(out.shape)
+        else:
             out = np.zeros((rows, p.width, 4), np.float32) if acc is None else np.ascontiguousarray(acc, np.float32).copy()
         _check(lib().mc_pathtrace_render(self._h, C.byref(p), _ptr(planes), planes.size // 12, _ptr(spheres),
                                          spheres.size // 12, _ptr(out)), "mc_pathtrace_render")
@@ -369,6 +403,12 @@ class Context:
         _check(lib().mc_mandelbrot_assemble_device_async(self._h, C.byref(p), d_tiles, iters_bytes, n_tiles, row_block,
                                                          tile_rows_padded, d_rgba or None, d_iters or None, stream or None),
                "mc_mandelbrot_assemble_device_async")
+
+    def assemble_rgba8_device(self, d_tiles_u8, W, H, n_tiles, row_block, tile_rows_padded, rotate180, d_rgba8, stream=0):
+        """Root side of the path tracer's RGBA8 exchange: gathered interleaved byte tiles -> the whole RGBA8 image, point-reflected
+        as saveRenderedImage leaves it when rotate180 is set."""
+        _check(lib().mc_assemble_rgba8_device_async(self._h, d_tiles_u8, W, H, n_tiles, row_block, tile_rows_padded, int(rotate180),
+                                                    d_rgba8, stream or None), "mc_assemble_rgba8_device_async")
 
     def deinterleave_rows_device(self, d_tiles, W, H, n_tiles, row_block, tile_rows_padded, bpp, d_out, stream=0):
         _check(lib().mc_deinterleave_rows_device_async(self._h, d_tiles, W, H, n_tiles, row_block, tile_rows_padded, bpp,
@@ -446,4 +486,20 @@ class Multi:
         out = np.empty((p.height, p.width, 4), np.float32)
         _check(lib().mc_multi_pathtrace_render(self._h, C.byref(p), _ptr(planes), planes.size // 12, _ptr(spheres),
                                                spheres.size // 12, _ptr(out)), "mc_multi_pathtrace_render")
+        return out
+
+    def pathtrace_rgba8(self, p, planes=None, spheres=None):
+        """mc_multi_pathtrace_render_rgba8: the finished image as saveRenderedImage converts and rotates it, 4 B/pixel exchanged."""
+        if planes is None or spheres is None:
+            planes, spheres = default_scene()
+        planes = np.ascontiguousarray(planes, np.float32).reshape(-1)
+        spheres = np.ascontiguousarray(spheres, np.float32).reshape(-1)
+        out = np.empty((p.height, p.width, 4), np.uint8)
+        _check(lib().mc_multi_pathtrace_render_rgba8(self._h, C.byref(p), _ptr(planes), planes.size // 12, _ptr(spheres),
+                                                     spheres.size // 12, _ptr(out)), "mc_multi_pathtrace_render_rgba8")
+        return out
+
+    def mandelbrot_rgba8(self, p):
+        out = np.empty((p.height, p.width, 4), np.uint8)
+        _check(lib().mc_multi_mandelbrot_render_rgba8(self._h, C.byref(p), _ptr(out)), "mc_multi_mandelbrot_render_rgba8")
         return out

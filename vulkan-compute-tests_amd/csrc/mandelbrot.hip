@@ -318,13 +318,15 @@ int mandelbrot_lut_device(mc_context* ctx, const mc_mandelbrot_params* p, hipStr
     return MC_OK;
 }
 
-int mandelbrot_launch(mc_context* ctx, const mc_mandelbrot_params* p, void* d_rgba, void* d_iters, hipStream_t s) {
+// warm = the cold-start warm-up (mc_context_warmup_mandelbrot): the tables of the REAL request are built and uploaded, then ONE 8 x 8
+// tile is run for at most 32 iterations into d_iters — enough for the runtime to load this code object and create the kernel.
+static int launch_impl(mc_context* ctx, const mc_mandelbrot_params* p, void* d_rgba, void* d_iters, hipStream_t s, bool warm) {
     if (!ctx || !p || (!d_rgba && !d_iters)) return MC_ERR_INVALID_ARGUMENT;
     if (!p->width || !p->height || !p->max_iter || p->row_end > p->height || p->row_begin >= p->row_end)
         return MC_ERR_INVALID_ARGUMENT;
     if (p->precision != MC_PRECISION_F32 && p->precision != MC_PRECISION_DS) return MC_ERR_INVALID_ARGUMENT;
     if (p->row_stride && (!p->row_block || p->row_block > p->row_stride)) return MC_ERR_INVALID_ARGUMENT;
-    if (d_rgba) {
+    if (d_rgba || warm) {
         int rc = ensure_lut(ctx, p, s);
         if (rc) return rc;
     }
@@ -339,17 +341,21 @@ int mandelbrot_launch(mc_context* ctx, const mc_mandelbrot_params* p, void* d_rg
     a.row_block = p->row_stride ? p->row_block : 0u; a.row_stride = p->row_stride;
     a.cx_hi = p->centre_x_hi; a.cx_lo = p->centre_x_lo; a.cy_hi = p->centre_y_hi; a.cy_lo = p->centre_y_lo;
     a.sx_hi = p->scale_x_hi; a.sx_lo = p->scale_x_lo; a.sy_hi = p->scale_y_hi; a.sy_lo = p->scale_y_lo;
-    a.out_rgba = (float4*)d_rgba;
+    a.out_rgba = warm ? nullptr : (float4*)d_rgba;
     const bool narrow = (p->flags & MC_MANDEL_ITERS_U16) != 0u;
     if (narrow && p->max_iter > 65535u) return MC_ERR_INVALID_ARGUMENT;
     a.out_iters = narrow ? nullptr : (uint32_t*)d_iters;
     a.out_iters16 = narrow ? (uint16_t*)d_iters : nullptr;
-    a.lut = d_rgba ? (const float4*)ctx->lut.ptr : nullptr;
+    a.lut = a.out_rgba ? (const float4*)ctx->lut.ptr : nullptr;
     const uint32_t rows = tile_rows(p->row_begin, p->row_end, a.row_block, a.row_stride);
     dim3 grid((p->width + 7u) / 8u, (rows + 7u) / 8u), block(64);
+    if (warm) {   // one tile, a handful of iterations; d_iters holds at least rows x W counts (the caller's scratch)
+        grid = dim3(1, 1);
+        a.max_iter = p->max_iter < 32u ? p->max_iter : 32u;
+    }
     a.tiles_x = grid.x;
     a.tile_order = nullptr;
-    if (ctx->debug_tile_order && ctx->debug_tile_order_n == (size_t)grid.x * grid.y) {   // experiment (mc_debug_mandelbrot_tile_order)
+    if (!warm && ctx->debug_tile_order && ctx->debug_tile_order_n == (size_t)grid.x * grid.y) {   // experiment (mc_debug_mandelbrot_tile_order)
         a.tile_order = (const uint32_t*)ctx->debug_tile_order;
         grid = dim3(grid.x * grid.y, 1);
     }
@@ -362,6 +368,14 @@ int mandelbrot_launch(mc_context* ctx, const mc_mandelbrot_params* p, void* d_rg
     }
     MC_HIP_TRY(hipGetLastError());
     return ctx->note_launch(s);
+}
+
+int mandelbrot_launch(mc_context* ctx, const mc_mandelbrot_params* p, void* d_rgba, void* d_iters, hipStream_t s) {
+    return launch_impl(ctx, p, d_rgba, d_iters, s, false);
+}
+
+int mandelbrot_warmup(mc_context* ctx, const mc_mandelbrot_params* p, void* d_iters_scratch, hipStream_t s) {
+    return launch_impl(ctx, p, nullptr, d_iters_scratch, s, true);
 }
 
 }  // namespace mc

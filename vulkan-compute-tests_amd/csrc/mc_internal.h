@@ -68,12 +68,16 @@ struct mc_context {
     hipEvent_t t_ev[3] = {nullptr, nullptr, nullptr};
     bool timing_valid = false;
     int mark(int k);      // records t_ev[k] on the context's stream (creating the events on first use)
+    // Two-phase host-buffer calls (mc_*_render_begin ... mc_render_end): what the pending render left in scratch for the copy.
+    const void* pending_src = nullptr;
+    size_t pending_bytes = 0;
 };
 
 namespace mc {
 
 // mandelbrot.hip
 int mandelbrot_launch(mc_context* ctx, const mc_mandelbrot_params* p, void* d_rgba, void* d_iters, hipStream_t s);
+int mandelbrot_warmup(mc_context* ctx, const mc_mandelbrot_params* p, void* d_iters_scratch, hipStream_t s);
 void mandelbrot_build_lut(uint32_t max_iter, const float k_color[4], float* lut);
 int mandelbrot_lut_device(mc_context* ctx, const mc_mandelbrot_params* p, hipStream_t s, const void** d_lut);
 // pathtrace.hip
@@ -87,6 +91,8 @@ int convert_rgba8_launch(mc_context* ctx, const void* d_rgba_f32, uint32_t W, ui
                          void* d_rgba8, hipStream_t s);
 int deinterleave_rows_launch(mc_context* ctx, const void* d_tiles, uint32_t W, uint32_t H, uint32_t n_tiles, uint32_t B,
                              uint32_t tile_rows_padded, uint32_t bytes_per_pixel, void* d_out, hipStream_t s);
+int assemble_rgba8_launch(mc_context* ctx, const void* d_tiles_u8, uint32_t W, uint32_t H, uint32_t n_tiles, uint32_t B,
+                          uint32_t tile_rows_padded, int rotate180, void* d_rgba8, hipStream_t s);
 int mandelbrot_assemble_launch(mc_context* ctx, const mc_mandelbrot_params* p, const void* d_tiles, uint32_t iters_bytes,
                                uint32_t n_tiles, uint32_t B, uint32_t tile_rows_padded, void* d_rgba, void* d_iters, hipStream_t s);
 

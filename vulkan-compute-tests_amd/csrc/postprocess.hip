@@ -77,6 +77,23 @@ __global__ void __launch_bounds__(256) mandelbrot_assemble_kernel(const T* __res
     }
 }
 
+// Path-tracer RGBA8 exchange on the root (multi-GPU, SURVEY §8(f)1: "only 4 B/px cross xGMI"): every rank converts its own tile
+// (convert_rgba8_kernel, no rotation) and sends 4 B/pixel; the root de-interleaves the gathered byte tiles and applies the point
+// reflection of pathtracerApp.h:236-243 in the same pass — output pixel (x, y) is storage pixel (W-1-x, H-1-y), except an odd
+// width's middle column, which the reference's swap loop (x < W/2 only) leaves where it was.  4 B read + 4 B written per pixel.
+__global__ void __launch_bounds__(256) assemble_rgba8_kernel(const uint32_t* __restrict__ tiles, uint32_t* __restrict__ dst, uint32_t W,
+                                                             uint32_t H, uint32_t n_tiles, uint32_t B, uint32_t tile_rows_padded,
+                                                             int rotate180) {
+    const size_t npix = (size_t)W * H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t r = (uint32_t)(i / W), x = (uint32_t)(i - (size_t)r * W);
+        if (rotate180 && !((W & 1u) && x == W / 2u)) { r = H - 1u - r; x = W - 1u - x; }
+        const uint32_t blk = r / B, j = r - blk * B;
+        const uint32_t t = blk % n_tiles, k = blk / n_tiles;
+        dst[i] = tiles[((size_t)t * tile_rows_padded + (size_t)k * B + j) * W + x];
+    }
+}
+
 }  // namespace
 
 int mandelbrot_assemble_launch(mc_context* ctx, const mc_mandelbrot_params* p, const void* d_tiles, uint32_t iters_bytes,
@@ -125,6 +142,21 @@ int deinterleave_rows_launch(mc_context* ctx, const void* d_tiles, uint32_t W, u
     else
         hipLaunchKernelGGL(deinterleave_rows_kernel<uint32_t>, dim3(blocks), dim3(256), 0, s, (const uint32_t*)d_tiles,
                            (uint32_t*)d_out, row_granules, H, n_tiles, B, tile_rows_padded);
+    MC_HIP_TRY(hipGetLastError());
+    return MC_OK;
+}
+
+int assemble_rgba8_launch(mc_context* ctx, const void* d_tiles_u8, uint32_t W, uint32_t H, uint32_t n_tiles, uint32_t B,
+                          uint32_t tile_rows_padded, int rotate180, void* d_rgba8, hipStream_t s) {
+    if (!ctx || !d_tiles_u8 || !d_rgba8 || !W || !H || !n_tiles || !B) return MC_ERR_INVALID_ARGUMENT;
+    // every storage row must exist in its tile: tile t holds the blocks t, t + n, ... — rank 0's tile is the longest
+    if (tile_rows_padded < tile_rows(0, H, B, B * n_tiles)) return MC_ERR_INVALID_ARGUMENT;
+    const size_t npix = (size_t)W * H;
+    uint32_t blocks = (uint32_t)((npix + 255) / 256);
+    const uint32_t cap = (uint32_t)ctx->props.multiProcessorCount * 8u;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(assemble_rgba8_kernel, dim3(blocks), dim3(256), 0, s, (const uint32_t*)d_tiles_u8, (uint32_t*)d_rgba8, W, H,
+                       n_tiles, B, tile_rows_padded, rotate180);
     MC_HIP_TRY(hipGetLastError());
     return MC_OK;
 }

@@ -6,7 +6,34 @@
 #include <chrono>
 #include <thread>
 
+#ifdef MC_HAVE_REFERENCE_PNG
+#include "lodepng.h"   // the reference checkout's own header (make REFERENCE=<checkout>: -I<checkout>/src/external/lodepng)
+#endif
+
+namespace {
+double msSince(std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+}
+}  // namespace
+
+bool ComputeApp::referencePngAvailable() {
+#ifdef MC_HAVE_REFERENCE_PNG
+    return true;
+#else
+    return false;
+#endif
+}
+
+void ComputeApp::setReferencePng(bool r) {
+    if (r && !referencePngAvailable())
+        throw std::runtime_error("--reference-png: this binary was built without the reference's PNG codec; rebuild with "
+                                 "`make REFERENCE=<checkout of pjhusky/vulkan-compute-tests>` (its lodepng is compiled where it lies)");
+    referencePng = r;
+}
+
 ComputeApp::~ComputeApp() {
+    if (warmThread.joinable()) warmThread.join();
+    if (allocThread.joinable()) allocThread.join();
     // cleanupVulkanResources (vulkanComputeApp.cpp:673-695)
     if (multi) mc_multi_destroy(multi);
     if (ctx) mc_context_destroy(ctx);
@@ -22,6 +49,9 @@ void ComputeApp::check(int status, const char* what) {
 }
 
 void ComputeApp::init() {
+    // The storage buffer first: pinning it needs the HIP runtime, whose start-up the helper thread shares with the calls below, and then
+    // runs beside context creation, warm-up and the render itself (K4: 629 MB, ~90 ms — profiles/r06_cold_timeline.txt).
+    if (overlapStart && storageBytes()) createBuffer(storageBytes());
     int n = 0;
     int rc = mc_device_count(&n);
     if (rc != MC_OK || n == 0) throw std::runtime_error("could not find a device with HIP support");   // cf. vulkanComputeApp.cpp:78
@@ -34,7 +64,23 @@ void ComputeApp::init() {
             mc_context_device_info(ctx, name, sizeof(name), &cus, &khz);
             printf("using device %d: %s (%d CUs)\n", deviceIndex, name, cus);
         }
+        if (overlapStart)   // the code object, tables and device scratch of the request run() will make, while the caller goes on
+            warmThread = std::thread([this] {
+                auto t0 = std::chrono::steady_clock::now();
+                warmStatus = warmup();
+                if (warmStatus != MC_OK) { const char* d = mc_last_error_detail(); warmError = d ? d : ""; }
+                times.warmupMs = msSince(t0);
+            });
     }
+}
+
+void ComputeApp::waitWarmup() {
+    if (!warmThread.joinable()) return;
+    auto t0 = std::chrono::steady_clock::now();
+    warmThread.join();
+    times.warmupWaitMs = msSince(t0);
+    if (warmStatus != MC_OK)   // a warm-up that fails would fail the render the same way: report it as the render's error
+        throw std::runtime_error(std::string("warm-up: ") + mc_error_string(warmStatus) + (warmError.empty() ? "" : " (" + warmError + ")"));
 }
 
 void HostStorage::allocate(uint64_t bytes) {
@@ -53,9 +99,30 @@ void HostStorage::allocate(uint64_t bytes) {
 
 void ComputeApp::createBuffer(uint64_t bufferSizeBytes) {
     auto t0 = std::chrono::steady_clock::now();
-    if (gpuPostprocess) rgba8.allocate(bufferSizeBytes / 4);   // 16 B/pixel of fp32 -> 4 B/pixel of RGBA8
-    else buffer.allocate(bufferSizeBytes);
-    times.allocMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    HostStorage& target = gpuPostprocess ? rgba8 : buffer;
+    const uint64_t bytes = gpuPostprocess ? bufferSizeBytes / 4 : bufferSizeBytes;   // 16 B/pixel of fp32 -> 4 B/pixel of RGBA8
+    if (!overlapStart) {
+        target.allocate(bytes);
+        times.allocMs += msSince(t0);
+        return;
+    }
+    if (allocStartedFor == bytes) return;            // init() started exactly this allocation already
+    waitStorage();                                   // (another size was in flight: finish it, then replace it)
+    allocStartedFor = bytes;
+    allocThread = std::thread([this, &target, bytes] {
+        auto t1 = std::chrono::steady_clock::now();
+        try { target.allocate(bytes); } catch (const std::exception& e) { allocError = e.what(); }
+        times.allocThreadMs = msSince(t1);
+    });
+    times.allocMs += msSince(t0);
+}
+
+void ComputeApp::waitStorage() {
+    if (!allocThread.joinable()) return;
+    auto t0 = std::chrono::steady_clock::now();
+    allocThread.join();
+    times.allocMs += msSince(t0);
+    if (!allocError.empty()) { std::string e = allocError; allocError.clear(); allocStartedFor = 0; throw std::runtime_error(e); }
 }
 
 void ComputeApp::convertStorage(std::vector<uint8_t>& image, uint32_t resx, uint32_t resy, float scale, bool rotate180) const {
@@ -67,7 +134,9 @@ void ComputeApp::run() {
     if (!quiet) { printf("in run()\n"); fflush(stdout); }
     createCommandBuffer();
     auto t0 = std::chrono::steady_clock::now();
+    waitWarmup();
     runCommandBuffer();
+    waitStorage();   // (every runCommandBuffer joins it before its copy; this covers one that had nothing to copy)
     auto t1 = std::chrono::steady_clock::now();
     lastRunMs = std::chrono::duration<double, std::milli>(t1 - t0).count();
     times.runMs = lastRunMs;
@@ -77,5 +146,11 @@ void ComputeApp::run() {
 }
 
 std::string ComputeApp::writePng(const char* filename, const uint8_t* rgba8, uint32_t w, uint32_t h) const {
+#ifdef MC_HAVE_REFERENCE_PNG
+    if (referencePng) {   // mandelbrotApp.h:181-183 / pathtracerApp.h:245-247: the reference's call and its error text
+        const unsigned error = lodepng::encode(filename, rgba8, w, h);
+        return error ? std::to_string(error) + ": " + lodepng_error_text(error) : std::string();
+    }
+#endif
     return pngwriter::encodeFile(filename, rgba8, w, h, pngThreads);
 }

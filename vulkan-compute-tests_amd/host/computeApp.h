@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mc_compute.h"
@@ -67,6 +68,17 @@ struct ComputeApp {
     // not copied to the host (storageBuffer() stays empty).  Same cast semantics, same bytes.
     void setGpuPostprocess(bool g) { gpuPostprocess = g; }
     void setPngThreads(int t) { pngThreads = t; }   // 0 = all cores, 1 = serial deflate; the host float -> u8 loop uses the same count
+    // saveRenderedImage through the REFERENCE's own codec — lodepng::encode(filename, image, w, h), mandelbrotApp.h:181 /
+    // pathtracerApp.h:245 — compiled from a reference checkout by `make REFERENCE=<checkout>` (nothing of it lives in this tree):
+    // the file is then the reference's byte for byte.  In a build without it the setter throws.
+    void setReferencePng(bool r);
+    static bool referencePngAvailable();
+    // Cold-start hiding, both on by default, switchable for measurements:
+    //   overlapStart   init() starts the storage buffer's page-locked allocation on a helper thread BEFORE the HIP runtime comes up
+    //                  (it is joined only where the render's result is copied to the host: the kernels write HBM), and a second
+    //                  helper issues mc_context_warmup_* as soon as the context exists (joined before run() touches the context);
+    //   false          the round-5 order: allocate in preRun() on the calling thread, first launch inside run().
+    void setOverlapStart(bool o) { overlapStart = o; }
     // saveRenderedImage's file: a standard PNG of exactly the RGBA8 pixels the reference converts its buffer to (mandelbrotApp.h:159-174,
     // pathtracerApp.h:202-243), deflated stripe-parallel by pngWriter.h.  The reference encodes the same pixels with its vendored
     // third-party codec (lodepng::encode, mandelbrotApp.h:181 / pathtracerApp.h:245): a reference tree that calls this library
@@ -76,12 +88,20 @@ struct ComputeApp {
     // Where the time of the last run() / saveRenderedImage() went (milliseconds; SURVEY §8d "end-to-end ... reported separately"):
     // device time of the kernels and of the device -> host copy (mc_context_last_timing; 0 for multi-GPU runs), the host
     // float -> u8 (+ rotation) loop, the PNG encoder + file write.
-    struct Timing { double allocMs = 0, runMs = 0, kernelMs = 0, copyMs = 0, convertMs = 0, pngMs = 0; };
+    // allocMs = time the CALLING thread spent on (or waiting for) the storage buffer; allocThreadMs = the allocation itself when a
+    // helper thread did it; warmupMs = the warm-up call on its helper thread, warmupWaitMs = what run() still had to wait for it.
+    struct Timing { double allocMs = 0, runMs = 0, kernelMs = 0, copyMs = 0, convertMs = 0, pngMs = 0, allocThreadMs = 0, warmupMs = 0,
+                    warmupWaitMs = 0; };
     const Timing& timing() const { return times; }
 
 protected:
     void createBuffer(uint64_t bufferSizeBytes);   // vulkanComputeApp.cpp:489-533: the output storage buffer (gpuPostprocess: a quarter
-                                                   // of it, for the RGBA8 image)
+                                                   // of it, for the RGBA8 image).  With overlapStart the allocation is (or was, by
+                                                   // init()) started on a helper thread; waitStorage() joins it
+    void waitStorage();                            // before the first use of buffer / rgba8: joins the allocation, rethrows its error
+    void waitWarmup();                             // before the first call on ctx after init(): joins the warm-up helper
+    virtual uint64_t storageBytes() const { return 0; }   // apps: sizeof(Pixel) * resx * resy — what preRun() will ask createBuffer for
+    virtual int warmup() { return MC_OK; }                // apps: mc_context_warmup_* for the request run() will make (helper thread)
     static void check(int status, const char* what);
 
     mc_context* ctx = nullptr;
@@ -91,6 +111,13 @@ protected:
     bool quiet = false;
     bool gpuPostprocess = false;
     int pngThreads = 0;
+    bool referencePng = false;
+    bool overlapStart = true;
+    std::thread allocThread, warmThread;
+    uint64_t allocStartedFor = 0;   // bytes the running / finished helper allocation was started for (0: none)
+    std::string allocError;
+    int warmStatus = MC_OK;
+    std::string warmError;
     HostStorage rgba8;            // gpuPostprocess: the RGBA8 image run() fills (page-locked too: 4 B/pixel cross PCIe), allocated by
                                   // preRun INSTEAD of the 16-B/pixel storage buffer, which such a run never copies to the host
     double lastRunMs = 0.0;

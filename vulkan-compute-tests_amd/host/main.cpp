@@ -3,10 +3,14 @@
 // Mandelbrot app renders 2000x2000; lifecycle init() -> preRun() -> run() -> saveRenderedImage();
 // std::runtime_error -> message + EXIT_FAILURE.  Options (never reinterpreting the two positional
 // arguments) expose what the reference hard-codes: --gpus N, --out FILE, --quiet, and per mode
-// --width/--height/--max-iter/--centre X Y/--scale SX SY/--precision f32|ds  or  --math strict|fast,
-// --large-sphere-walls, --sphere-precision f32|fp64|ds|df64 (the reference's compile-time precision experiment).
+// --width/--height/--max-iter/--centre X Y/--scale SX SY/--precision f32|ds  or  --math strict|fast|careful,
+// --large-sphere-walls, --sphere-precision f32|fp64|ds|df64 (the reference's compile-time precision experiment);
+// --reference-png writes the file through the reference's own lodepng (a build with `make REFERENCE=<checkout>`): its bytes.
+// A value none of these lists name is an error (EXIT_FAILURE) — never a silent default.
 #include <chrono>
 #include <cstdlib>
+#include <initializer_list>
+#include <utility>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -29,7 +33,7 @@ int main(int argc, char* argv[]) {
     // split options from positional arguments
     std::vector<const char*> pos;
     int gpus = 1;
-    bool quiet = false, gpuPost = false, timingJson = false;
+    bool quiet = false, gpuPost = false, timingJson = false, referencePng = false, overlapStart = true;
     int pngThreads = 0;
     const char* outFile = nullptr;
     uint32_t width = 2000, height = 2000, maxIter = 128, precision = MC_PRECISION_F32, mathMode = MC_PT_MATH_STRICT;
@@ -39,6 +43,13 @@ int main(int argc, char* argv[]) {
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto need = [&](int n) { if (i + n >= argc) { printf("missing value for %s\n", a.c_str()); exit(EXIT_FAILURE); } };
+        // one of a closed list of words -> its code; anything else ends the run (a typo must not render something else)
+        auto choice = [&](const char* v, std::initializer_list<std::pair<const char*, uint32_t>> words) -> uint32_t {
+            std::string all;
+            for (const auto& w : words) { if (std::strcmp(v, w.first) == 0) return w.second; all += (all.empty() ? "" : " | ") + std::string(w.first); }
+            printf("%s %s: not one of %s\n", a.c_str(), v, all.c_str());
+            exit(EXIT_FAILURE);
+        };
         if (a == "--gpus") { need(1); gpus = atoi(argv[++i]); }
         else if (a == "--out") { need(1); outFile = argv[++i]; }
         else if (a == "--quiet") quiet = true;
@@ -53,13 +64,19 @@ int main(int argc, char* argv[]) {
         else if (a == "--max-iter") { need(1); maxIter = (uint32_t)atoi(argv[++i]); }
         else if (a == "--centre") { need(2); cx = atof(argv[++i]); cy = atof(argv[++i]); viewSet = true; }
         else if (a == "--scale") { need(2); sx = atof(argv[++i]); sy = atof(argv[++i]); viewSet = true; }
-        else if (a == "--precision") { need(1); precision = std::strcmp(argv[++i], "ds") == 0 ? MC_PRECISION_DS : MC_PRECISION_F32; }
-        else if (a == "--math") { need(1); mathMode = std::strcmp(argv[++i], "fast") == 0 ? MC_PT_MATH_FAST : MC_PT_MATH_STRICT; }
+        else if (a == "--precision") { need(1); precision = choice(argv[++i], {{"f32", MC_PRECISION_F32}, {"ds", MC_PRECISION_DS}}); }
+        else if (a == "--math") {   // strict (the default: bit-identical to the oracle) | fast | careful (mc_compute.h MC_PT_MATH_*)
+            need(1);
+            mathMode = choice(argv[++i], {{"strict", MC_PT_MATH_STRICT}, {"fast", MC_PT_MATH_FAST}, {"careful", MC_PT_MATH_FAST_CAREFUL}});
+        }
+        else if (a == "--reference-png") referencePng = true;       // the reference's lodepng::encode (make REFERENCE=<checkout>)
+        else if (a == "--serial-start") overlapStart = false;        // measurements: the round-5 start-up order (no helper threads)
         else if (a == "--large-sphere-walls") largeSpheres = true;   // TEST_PRECISION_WITH_LARGE_SPHERE_WALLS (pathtracerApp.h:11)
         else if (a == "--sphere-precision") {                        // which #if branch of pathTracer.comp:132-256 is active
-            need(1); std::string v = argv[++i];
-            spherePrec = v == "fp64" ? MC_PT_PREC_FP64 : v == "ds" ? MC_PT_PREC_DS : v == "df64" ? MC_PT_PREC_DF64 : MC_PT_PREC_F32;
+            need(1);
+            spherePrec = choice(argv[++i], {{"f32", MC_PT_PREC_F32}, {"fp64", MC_PT_PREC_FP64}, {"ds", MC_PT_PREC_DS}, {"df64", MC_PT_PREC_DF64}});
         }
+        else if (a.size() > 2 && a[0] == '-' && a[1] == '-') { printf("unknown option %s\n", a.c_str()); exit(EXIT_FAILURE); }
         else pos.push_back(argv[i]);
     }
     (void)width; (void)height; (void)maxIter; (void)precision; (void)mathMode; (void)cx; (void)cy; (void)sx; (void)sy; (void)viewSet; (void)largeSpheres; (void)spherePrec;
@@ -82,6 +99,13 @@ int main(int argc, char* argv[]) {
     app.setQuiet(quiet);
     app.setGpuPostprocess(gpuPost);
     app.setPngThreads(pngThreads);
+    app.setOverlapStart(overlapStart);
+    if (referencePng && !ComputeApp::referencePngAvailable()) {   // said before anything is rendered
+        printf("--reference-png: this binary was built without the reference's PNG codec; rebuild with `make REFERENCE=<checkout of "
+               "pjhusky/vulkan-compute-tests>` (its src/external/lodepng is compiled where it lies)\n");
+        return EXIT_FAILURE;
+    }
+    app.setReferencePng(referencePng);
 
     const auto tStart = std::chrono::steady_clock::now();
     auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
@@ -102,9 +126,13 @@ int main(int argc, char* argv[]) {
                             // which kernel + copy are device time; convert = float -> u8 (+ rotation) on the host (0: done on the device);
                             // png = encode + write; total = process wall time up to here
             const ComputeApp::Timing& t = app.timing();
+            // (alloc = what the calling thread spent on / waiting for the storage buffer; alloc_thread, warmup = the helper threads'
+            //  own durations, warmup_wait = what run() still waited for the warm-up: overlapped start-up, computeApp.h)
             printf("{\"timing_ms\": {\"init\": %.3f, \"alloc\": %.3f, \"run\": %.3f, \"kernel\": %.3f, \"copy\": %.3f, \"convert\": %.3f, "
-                   "\"png\": %.3f, \"total\": %.3f}, \"gpu_postprocess\": %s, \"gpus\": %d}\n",
-                   initMs, t.allocMs, t.runMs, t.kernelMs, t.copyMs, t.convertMs, t.pngMs, since(tStart), gpuPost ? "true" : "false", gpus);
+                   "\"png\": %.3f, \"total\": %.3f, \"alloc_thread\": %.3f, \"warmup\": %.3f, \"warmup_wait\": %.3f}, "
+                   "\"gpu_postprocess\": %s, \"gpus\": %d, \"overlap_start\": %s, \"reference_png\": %s}\n",
+                   initMs, t.allocMs, t.runMs, t.kernelMs, t.copyMs, t.convertMs, t.pngMs, since(tStart), t.allocThreadMs, t.warmupMs,
+                   t.warmupWaitMs, gpuPost ? "true" : "false", gpus, overlapStart ? "true" : "false", referencePng ? "true" : "false");
         }
     } catch (const std::runtime_error& e) {
         printf("%s\n", e.what());

@@ -40,14 +40,27 @@ struct MandelbrotApp : public ComputeApp {
         params.row_begin = 0; params.row_end = resy;
     }
 
+    virtual uint64_t storageBytes() const override { return bufferSize; }
+    virtual int warmup() override {   // helper thread of init(): tables + code object of the request run() will make
+        mc_mandelbrot_params q = params;
+        q.k_color[0] = 0.1f; q.k_color[1] = 0.7f; q.k_color[2] = 0.6f; q.k_color[3] = 0.0f;   // as createCommandBuffer sets it
+        q.row_begin = 0; q.row_end = resy;
+        return mc_context_warmup_mandelbrot(ctx, &q, gpuPostprocess ? 1 : 0);
+    }
+
+    // gpuPostprocess: render + float->u8 on the device, 4 B/pixel cross PCIe instead of 16.  One GPU: launch, THEN wait for the
+    // storage buffer (allocated on a helper thread since init(): K4's 629 MB take longer to pin than its render takes), then copy.
     virtual void runCommandBuffer() override {
-        if (gpuPostprocess) {   // render + float->u8 on the device: 4 B/pixel cross PCIe instead of 16
-            if (multi) check(mc_multi_mandelbrot_render_rgba8(multi, &params, rgba8.bytes()), "mc_multi_mandelbrot_render_rgba8");
-            else check(mc_mandelbrot_render_rgba8(ctx, &params, rgba8.bytes()), "mc_mandelbrot_render_rgba8");
+        if (multi) {
+            waitStorage();
+            if (gpuPostprocess) check(mc_multi_mandelbrot_render_rgba8(multi, &params, rgba8.bytes()), "mc_multi_mandelbrot_render_rgba8");
+            else check(mc_multi_mandelbrot_render(multi, &params, buffer.data(), nullptr), "mc_multi_mandelbrot_render");
             return;
         }
-        if (multi) check(mc_multi_mandelbrot_render(multi, &params, buffer.data(), nullptr), "mc_multi_mandelbrot_render");
-        else check(mc_mandelbrot_render(ctx, &params, buffer.data(), nullptr), "mc_mandelbrot_render");
+        check(mc_mandelbrot_render_begin(ctx, &params, gpuPostprocess ? 1 : 0), "mc_mandelbrot_render_begin");
+        waitStorage();
+        if (gpuPostprocess) check(mc_render_end(ctx, rgba8.bytes(), rgba8.sizeBytes()), "mc_render_end");
+        else check(mc_render_end(ctx, buffer.data(), buffer.sizeBytes()), "mc_render_end");
     }
 
     // mandelbrotApp.h:149-170: u8 = static_cast<uint8_t>(scale * c), alpha 255.  The cast is UB out of

@@ -38,7 +38,7 @@ struct PathtracerApp : public ComputeApp {
     virtual ~PathtracerApp() {}
 
     // -- additions --
-    void setMathMode(uint32_t mode) { params.math_mode = mode; }   // MC_PT_MATH_STRICT / MC_PT_MATH_FAST
+    void setMathMode(uint32_t mode) { params.math_mode = mode; }   // MC_PT_MATH_STRICT / MC_PT_MATH_FAST / MC_PT_MATH_FAST_CAREFUL
     // The reference's precision experiment (pathtracerApp.h:11, emulateDouble.h.glsl:13-26), a run-time switch here:
     // which sphere-test branch of pathTracer.comp:132-256 is active, and the sphere-walled scene of :28-35.
     void setSpherePrecision(uint32_t prec) { params.flags = (params.flags & ~MC_PT_PRECISION(0xf)) | MC_PT_PRECISION(prec); }
@@ -79,21 +79,31 @@ struct PathtracerApp : public ComputeApp {
         params.row_begin = 0; params.row_end = resy;
     }
 
+    virtual uint64_t storageBytes() const override { return bufferSize; }
+    virtual int warmup() override {   // helper thread of init(): what run() is going to ask for (the setters were called before init())
+        mc_pathtrace_params q = params;
+        q.width = resx; q.height = resy; q.spp = (uint32_t)spp; q.sample_begin = 0; q.sample_end = q.spp; q.row_begin = 0; q.row_end = resy;
+        return mc_context_warmup_pathtrace(ctx, &q, planes.data(), (uint32_t)planes.size() / 12, spheres.data(),
+                                           (uint32_t)spheres.size() / 12, gpuPostprocess ? 1 : 0);
+    }
+
+    // gpuPostprocess: render + float->u8 + 180-degree rotation on the device (pathtracerApp.h:202-243), 4 B/pixel copied.
+    // One GPU: launch, THEN wait for the storage buffer (its allocation runs on a helper thread since init()), then copy.
     virtual void runCommandBuffer() override {
-        if (gpuPostprocess) {   // render + float->u8 + 180-degree rotation on the device (pathtracerApp.h:202-243)
-            const uint32_t np = (uint32_t)planes.size() / 12, ns = (uint32_t)spheres.size() / 12;
-            if (multi) check(mc_multi_pathtrace_render_rgba8(multi, &params, planes.data(), np, spheres.data(), ns, rgba8.bytes()),
-                             "mc_multi_pathtrace_render_rgba8");
-            else check(mc_pathtrace_render_rgba8(ctx, &params, planes.data(), np, spheres.data(), ns, rgba8.bytes()),
-                       "mc_pathtrace_render_rgba8");
+        const uint32_t np = (uint32_t)planes.size() / 12, ns = (uint32_t)spheres.size() / 12;
+        if (multi) {
+            waitStorage();
+            if (gpuPostprocess) check(mc_multi_pathtrace_render_rgba8(multi, &params, planes.data(), np, spheres.data(), ns, rgba8.bytes()),
+                                      "mc_multi_pathtrace_render_rgba8");
+            else check(mc_multi_pathtrace_render(multi, &params, planes.data(), np, spheres.data(), ns, buffer.data()),
+                       "mc_multi_pathtrace_render");
             return;
         }
-        if (multi)
-            check(mc_multi_pathtrace_render(multi, &params, planes.data(), (uint32_t)planes.size() / 12, spheres.data(),
-                                            (uint32_t)spheres.size() / 12, buffer.data()), "mc_multi_pathtrace_render");
-        else
-            check(mc_pathtrace_render(ctx, &params, planes.data(), (uint32_t)planes.size() / 12, spheres.data(),
-                                      (uint32_t)spheres.size() / 12, buffer.data()), "mc_pathtrace_render");
+        check(mc_pathtrace_render_begin(ctx, &params, planes.data(), np, spheres.data(), ns, gpuPostprocess ? 1 : 0),
+              "mc_pathtrace_render_begin");
+        waitStorage();
+        if (gpuPostprocess) check(mc_render_end(ctx, rgba8.bytes(), rgba8.sizeBytes()), "mc_render_end");
+        else check(mc_render_end(ctx, buffer.data(), buffer.sizeBytes()), "mc_render_end");
     }
 
     // pathtracerApp.h:202-223

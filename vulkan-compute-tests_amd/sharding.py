@@ -4,7 +4,9 @@ The path shards with NO data-path collective during the render: every pixel is i
 absolute coordinates (pathTracer.comp:357,393; mandelbrot.comp:30-38), so rank r renders the interleaved
 ROW_BLOCK-row blocks r, r+n, r+2n, ... of the storage buffer with the GLOBAL (W, H) and gets the same bits as a
 single-GPU render.  One exchange step follows: the tiles are gathered to rank 0 (RCCL over xGMI when the backend is "nccl")
-— the path tracer's fp32 vec4 tiles, re-assembled with mc_deinterleave_rows_device_async; for the Mandelbrot only the
+— the path tracer's fp32 vec4 tiles, re-assembled with mc_deinterleave_rows_device_async, or the RGBA8 tiles
+every rank has converted itself, 4 B/pixel, which rank 0 de-interleaves and point-reflects with mc_assemble_rgba8_device_async
+into the image saveRenderedImage would write; for the Mandelbrot only the
 iteration counts (uint16 for max_iter <= 65535: 2 B/pixel instead of 16), from which rank 0 rebuilds the vec4 buffer through the
 colour table (mc_mandelbrot_assemble_device_async: the colour is a function of the count alone, mandelbrot.comp:50-59).
 Samples are never split across ranks: the fp32 accumulation order is part of the parity contract.
@@ -75,18 +77,26 @@ class Exchange:
     queued so far; Work.wait() makes the CURRENT stream wait for it, so it is called under the side stream.  gloo
     (rehearsal, ranks sharing a GPU): the tile is staged through the host and the call is synchronous."""
 
-    def __init__(self, rank, n, tile_shape, dtype, device, dst=0):
+    def __init__(self, rank, n, tile_shape, dtype, device, dst=0, exchange_when_alone=False):
         self.rank, self.n, self.dst = rank, n, dst
-        self.gloo = n > 1 and dist.get_backend() == "gloo"
-        self.tiles = [torch.zeros(tile_shape, dtype=dtype, device=device) for _ in range(2 if n > 1 else 1)]
+        # A world of one has nothing to exchange (bench.py at N = 1).  exchange_when_alone=True sends it through the collective
+        # all the same — a gather with itself — so that the asynchronous RCCL branch below can be driven on a ONE-GPU box against the
+        # real backend (tests/test_gpu_multi.py): the same calls, streams and events as with N > 1.
+        self.active = n > 1 or exchange_when_alone
+        self.gloo = self.active and dist.get_backend() == "gloo"
+        self.tiles = [torch.zeros(tile_shape, dtype=dtype, device=device) for _ in range(2 if self.active else 1)]
         self.recv = ([torch.empty((n,) + tuple(tile_shape), dtype=dtype, device=device) for _ in range(2)]
-                     if n > 1 and rank == dst else None)
-        self.side = torch.cuda.Stream(device=device) if (n > 1 and torch.device(device).type == "cuda") else None
+                     if self.active and rank == dst else None)
+        self.side = torch.cuda.Stream(device=device) if (self.active and torch.device(device).type == "cuda") else None
         self.pending = [None, None]
         self.bytes_per_rank = self.tiles[0].numel() * self.tiles[0].element_size()
         # MC_BENCH_SYNC_EXCHANGE=1 (or an exception from the asynchronous path, reported on stderr): the same collective issued
-        # synchronously on the render stream — no overlap, same bytes, same result.  Which one ran is reported by bench.py.
+        # synchronously on the render stream — no overlap, same bytes, same result.  Which one ran is reported by bench.py, and a
+        # FALLBACK (`fell_back`: the asynchronous path was meant to run and raised) makes bench.py exit non-zero unless
+        # --allow-sync-exchange was given: the collectives are completed first so that no rank is left waiting in one.
         self.sync_mode = os.environ.get("MC_BENCH_SYNC_EXCHANGE", "0") == "1"
+        self.fell_back = False
+        self.fallback_error = None
 
     def tile(self, i):
         """The tile buffer of step i.  The render stream is made to wait (on the device, not the host) for the exchange that
@@ -101,7 +111,7 @@ class Exchange:
         return torch.cuda.current_stream().cuda_stream if self.tiles[0].is_cuda else 0
 
     def submit(self, i, assemble=None, done_event=None):
-        if self.n == 1:
+        if not self.active:
             return
         k = i % 2
         tile = self.tiles[k]
@@ -131,10 +141,12 @@ class Exchange:
                         done_event.record()
                 self.pending[k] = ev
                 return
-            except Exception as e:              # noqa: BLE001 — keep the job alive: the exchange is correct either way
+            except Exception as e:              # noqa: BLE001 — complete the collective (every rank is in it); bench.py then fails the job
                 print(f"[sharding.Exchange] asynchronous exchange failed on rank {self.rank} ({e!r}); continuing synchronously",
                       file=sys.stderr, flush=True)
                 self.sync_mode = True
+                self.fell_back = True
+                self.fallback_error = repr(e)
                 if work is not None:            # the collective was issued: complete it on the render stream
                     work.wait()
                     if self.rank == self.dst and assemble is not None:
