@@ -163,7 +163,7 @@ def lavapipe_probe():
 APP_DIR = os.path.join(ROOT, "vulkan-compute-tests_amd", "bin")
 
 
-def app_command(cfg_name, route, out_png, math="fast"):
+def app_command(cfg_name, route, out_png, math="fast", extra=()):
     """The standalone app's command line for a BASELINE configuration (the reference's main.cpp surface + this repo's options)."""
     cfg = CONFIGS[cfg_name]
     if cfg["kind"] == "pt":
@@ -177,10 +177,10 @@ def app_command(cfg_name, route, out_png, math="fast"):
     cmd += ["--quiet", "--timing-json", "--out", out_png]
     if route == "rgba8":
         cmd += ["--gpu-postprocess"]
-    return cmd
+    return cmd + list(extra)
 
 
-def end_to_end(cfg_names=("K2", "K4"), math="fast", probe=None):
+def end_to_end(cfg_names=("K2", "K4"), math="fast", probe=None, extra=()):
     """"end-to-end seconds incl. gather, D2H, convert, PNG (reported separately)" — the standalone apps (the reference's
     main.cpp flow: init, preRun, run, saveRenderedImage) run as child processes with --timing-json, through both routes:
       host_buffer: run() fills the application's pinned 16-B/pixel storage buffer (mc_*_render), saveRenderedImage converts on the host
@@ -198,7 +198,7 @@ def end_to_end(cfg_names=("K2", "K4"), math="fast", probe=None):
             for route in ("host_buffer", "rgba8"):
                 png = os.path.join(tmp, f"{name}_{route}.png")
                 try:
-                    p = subprocess.run(app_command(name, route, png, math), capture_output=True, text=True, timeout=600)
+                    p = subprocess.run(app_command(name, route, png, math, extra), capture_output=True, text=True, timeout=600)
                 except (OSError, subprocess.SubprocessError) as e:     # the app is not built / did not finish: say so, keep the line
                     entry[route] = {"error": repr(e)[-300:]}
                     continue
@@ -218,7 +218,10 @@ def end_to_end(cfg_names=("K2", "K4"), math="fast", probe=None):
             out[name] = entry
     out["note"] = ("one cold app process per entry (bin/pathtracer, bin/mandelbrot --timing-json); ms; init = HIP start-up + context, alloc = "
                    "the pinned storage buffer (mc_host_alloc), run = the blocking render call = kernel + copy (device time) + launch / sync, "
-                   "convert = host float -> u8 (+ rotation; 0 when done on the device), png = encode + write, total = process wall time")
+                   "convert = host float -> u8 (+ rotation; 0 when done on the device), png = encode + write, total = process wall time.  "
+                   "Round 6: the apps warm the kernel family up on a helper thread from init() (warmup; warmup_wait = what run() still waited "
+                   "for it) and allocate the storage buffer inside run(), while the device renders: `kernel` no longer contains the code "
+                   "object's first use, `run` contains `alloc`")
     return out
 
 

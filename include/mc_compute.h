@@ -64,8 +64,10 @@ int mc_context_device_info(mc_context* ctx, char* name, size_t name_len, int* co
  * HOST_VISIBLE | HOST_COHERENT (VulkanComputeApp::createBuffer, vulkanComputeApp.cpp:489-533; mapped by getRenderedImage,
  * mandelbrotApp.h:153 / pathtracerApp.h:206; freed at vulkanComputeApp.cpp:684-685).  The buffer lives in HBM while the kernels
  * write it, so 16 B/pixel cross PCIe once, at the end of mc_*_render; into page-locked memory that copy needs no staging and no
- * page pinning by the runtime.  Any host pointer is accepted by the render calls — a pageable one is copied at the same rate on this
- * platform once its pages are resident (profiles/r05_d2h_probe.txt) — so these two are an ownership convention, not a requirement.
+ * page pinning by the runtime.  Buffers of 32 MB and more are huge-page mappings first-touched in parallel and then registered with
+ * the runtime (K4's 629 MB: 4 ms instead of hipHostMalloc's 86, same copy rate; profiles/r06_hostmem_probe.txt), smaller ones
+ * hipHostMalloc.  Any host pointer is accepted by the render calls — a pageable one is copied at nearly the same rate once its pages
+ * are resident, at half of it while they are not — so these two are an ownership convention, not a requirement.
  * Usable before any context exists; the memory is visible to every device of the node. */
 int mc_host_alloc(size_t bytes, void** out_ptr);
 int mc_host_free(void* ptr);

@@ -6,15 +6,20 @@
 //   alloc the K4-sized pinned buffer on a helper thread started first; the main thread creates the context and renders K2
 //   warm  a helper thread with a context of its own renders the 16 x 8 x 16 image while the main thread creates its context and
 //         allocates; joined before the main thread's K2
-//   both  alloc + warm together (what the apps do from round 6 on)
+//   both  alloc + warm together
+//   hostmem  what the storage buffer's host side costs, 629 MB / 157 MB / 8.64 MB, after the runtime is up: hipHostMalloc; mmap + first
+//         touch on T threads (+ MADV_HUGEPAGE) + hipHostRegister; plain mmap left untouched — each followed by two device -> host copies
 //   build: hipcc -O2 -std=c++17 -I include tools/cold_timeline.cpp -o tools/bin/cold_timeline -L vulkan-compute-tests_amd/lib -lmc_compute
 //          -Wl,-rpath,$PWD/vulkan-compute-tests_amd/lib -lpthread
 //   GPU box: for m in seq alloc warm both seq; do tools/bin/cold_timeline $m; done > gpurun_out/r06_cold_timeline.txt
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <chrono>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -56,10 +61,65 @@ static void k2(mc_context* c, float* buf, const char* label) {
     printf("         (device: kernel %.2f ms, copy %.2f ms)\n", k, cp);
 }
 
+static double timed(const std::function<void()>& f) { const double a = now_ms(); f(); return now_ms() - a; }
+
+static void touch_parallel(char* p, size_t bytes, int threads) {
+    std::vector<std::thread> th;
+    const size_t chunk = ((bytes / threads + 4095) / 4096) * 4096;
+    for (int t = 0; t < threads; t++)
+        th.emplace_back([=] { for (size_t i = (size_t)t * chunk; i < std::min(bytes, (size_t)(t + 1) * chunk); i += 4096) p[i] = 0; });
+    for (auto& x : th) x.join();
+}
+
+static int hostmem() {
+    (void)hipSetDevice(0);
+    hipStream_t s;
+    (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    const size_t sizes[3] = {7680ull * 5120 * 16, 7680ull * 5120 * 4, 900ull * 600 * 16};
+    void* d = nullptr;
+    (void)hipMalloc(&d, sizes[0]);
+    (void)hipMemset(d, 1, sizes[0]);
+    (void)hipDeviceSynchronize();
+    auto copy2 = [&](void* h, size_t n, double out[2]) {
+        for (int k = 0; k < 2; k++) out[k] = timed([&] { (void)hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s); (void)hipStreamSynchronize(s); });
+    };
+    printf("# %-44s %9s %9s %9s %9s %9s   (ms)\n", "host side of the storage buffer", "alloc", "touch", "register", "copy 1", "copy 2");
+    for (size_t n : sizes) {
+        printf("%.2f MB\n", n / 1e6);
+        double c[2];
+        { void* h = nullptr; const double a = timed([&] { (void)hipHostMalloc(&h, n, hipHostMallocPortable); }); copy2(h, n, c);
+          printf("  %-44s %9.2f %9s %9s %9.2f %9.2f\n", "hipHostMalloc", a, "-", "-", c[0], c[1]); (void)hipHostFree(h); }
+        for (int huge = 0; huge < 2; huge++)
+            for (int threads : {1, 4, 8, 16}) {
+                char* h = nullptr;
+                const double a = timed([&] { h = (char*)mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+                                             if (huge) madvise(h, n, MADV_HUGEPAGE); });
+                const double t = timed([&] { touch_parallel(h, n, threads); });
+                hipError_t e = hipSuccess;
+                const double r = timed([&] { e = hipHostRegister(h, n, hipHostRegisterPortable); });
+                copy2(h, n, c);
+                char label[96];
+                snprintf(label, sizeof label, "mmap%s + touch x%d + hipHostRegister%s", huge ? " + MADV_HUGEPAGE" : "", threads, e == hipSuccess ? "" : " (FAILED)");
+                printf("  %-44s %9.2f %9.2f %9.2f %9.2f %9.2f\n", label, a, t, r, c[0], c[1]);
+                if (e == hipSuccess) (void)hipHostUnregister(h);
+                munmap(h, n);
+            }
+        for (int threads : {0, 16}) {
+            char* h = (char*)mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            const double t = threads ? timed([&] { touch_parallel(h, n, threads); }) : 0.0;
+            copy2(h, n, c);
+            printf("  %-44s %9.2f %9.2f %9s %9.2f %9.2f\n", threads ? "mmap + touch x16, pageable (no register)" : "mmap untouched, pageable", 0.0, t, "-", c[0], c[1]);
+            munmap(h, n);
+        }
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
     g_t0 = std::chrono::steady_clock::now();
     const std::string mode = argc > 1 ? argv[1] : "seq";
     printf("mode %s\n", mode.c_str());
+    if (mode == "hostmem") return hostmem();
     mc_pathtrace_default_scene(&g_pl, &g_np, &g_sp, &g_ns);
     const size_t k2_bytes = 900ull * 600 * 16, k4_bytes = 7680ull * 5120 * 16;
     void *h2 = nullptr, *h4 = nullptr;

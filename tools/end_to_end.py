@@ -3,7 +3,9 @@
 reported separately").  Runs the standalone apps — the reference's main.cpp flow: init, preRun, run, saveRenderedImage — as child
 processes with --timing-json for K2 (path trace 900 x 600 x 500), K1 and K4 (Mandelbrot 3200 x 2400 / 7680 x 5120 two-float), through
 both routes (bench.py: end_to_end), three times each (the best total is shown), next to a pinned device -> host copy of the same size.
-    GPU box:  python tools/end_to_end.py > gpurun_out/r05_end_to_end.txt"""
+Round 6: every configuration twice — the apps' overlapped start (kernel family warmed up on a helper thread from init(), storage
+buffer allocated inside run() while the device renders) and `--serial-start`, the round-5 order, on the same build.
+    GPU box:  python tools/end_to_end.py > gpurun_out/r06_end_to_end.txt"""
 import os
 import sys
 
@@ -22,17 +24,22 @@ def main():
     print("# one cold app process per row, best total of 3; milliseconds.  init = HIP start-up + context; alloc = the pinned storage buffer; kernel / copy = device")
     print("# time of the render (+ on-device conversion) and of the device -> host copy; convert = host float -> u8 (+ rotation), row stripes on all cores;")
     print("# png = encode + write (stripe-parallel zlib); total = process wall time from main() to the file being written")
-    print(f"# {'config':6s} {'route':12s} {'init':>8s} {'alloc':>8s} {'kernel':>9s} {'copy':>8s} {'GB/s':>6s} {'vs probe':>8s} {'convert':>8s} {'png':>8s} {'total':>9s}   png bytes")
+    print("# start: overlap = round 6 (warm-up on a helper thread from init(); the storage buffer allocated inside run(), after the launch), serial = --serial-start")
+    print("# (the round-5 order); alloc = the storage buffer (mc_host_alloc); warm = the warm-up call on its helper thread, w.wait = what run() still waited for it")
+    print(f"# {'config':6s} {'route':12s} {'start':8s} {'init':>7s} {'alloc':>7s} {'warm':>6s} {'w.wait':>6s} {'run':>8s} {'kernel':>8s} {'copy':>7s} {'GB/s':>6s} "
+          f"{'convert':>8s} {'png':>7s} {'total':>8s}   png bytes")
     for name in cfgs:
-        runs = [bench.end_to_end((name,), "fast", probe) for _ in range(3)]
-        for route in ("host_buffer", "rgba8"):
-            ok = [r[name][route] for r in runs if "error" not in r[name][route]]
-            if not ok:
-                print(f"  {name:6s} {route:12s} FAILED {runs[0][name][route]}")
-                continue
-            t = min(ok, key=lambda x: x["total"])
-            print(f"  {name:6s} {route:12s} {t['init']:8.1f} {t['alloc']:8.1f} {t['kernel']:9.2f} {t['copy']:8.2f} {t['d2h_gbps'] or 0:6.1f} "
-                  f"{t.get('d2h_vs_probe') or 0:8.2f} {t['convert']:8.1f} {t['png']:8.1f} {t['total']:9.1f}   {t['png_bytes']}", flush=True)
+        for start, extra in (("overlap", ()), ("serial", ("--serial-start",))):
+            runs = [bench.end_to_end((name,), "fast", probe, extra) for _ in range(3)]
+            for route in ("host_buffer", "rgba8"):
+                ok = [r[name][route] for r in runs if "error" not in r[name][route]]
+                if not ok:
+                    print(f"  {name:6s} {route:12s} {start:8s} FAILED {runs[0][name][route]}")
+                    continue
+                t = min(ok, key=lambda x: x["total"])
+                print(f"  {name:6s} {route:12s} {start:8s} {t['init']:7.1f} {t['alloc']:7.1f} {t['warmup']:6.1f} {t['warmup_wait']:6.1f} "
+                      f"{t['run']:8.2f} {t['kernel']:8.2f} {t['copy']:7.2f} {t['d2h_gbps'] or 0:6.1f} {t['convert']:8.1f} {t['png']:7.1f} {t['total']:8.1f}   {t['png_bytes']}",
+                      flush=True)
 
 
 if __name__ == "__main__":

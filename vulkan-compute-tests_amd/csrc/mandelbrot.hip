@@ -42,9 +42,6 @@ struct MandelArgs {
     // operation sequence (mandelbrot.comp:30-31,38): fp32 [cx[W] | cy[H]], two-float [cx(hi,lo)[W] | cy(hi,lo)[H]].
     // Replaces two IEEE divisions (~50 instructions) per pixel; exterior tiles only run a handful of iterations.
     const float* __restrict__ c_tab;
-    // optional dispatch order: workgroup b renders tile tile_order[b] (index = tile_y * tiles_x + tile_x); null = natural order
-    const uint32_t* __restrict__ tile_order;
-    uint32_t tiles_x;
 };
 
 // ---- per-pixel state machines: step() advances one iteration and reports "escaped now" ----------
@@ -222,8 +219,7 @@ __global__ void __launch_bounds__(64) mandelbrot_kernel(MandelArgs a) {
     // max_iter iterations apart, so the unit the hardware schedules is the tile itself: a 4-wave block would keep its
     // place on the CU until its slowest tile is through (K1: 0.208 -> 0.200 ms).
     const uint32_t lane = threadIdx.x;
-    uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y;
-    if (a.tile_order) { const uint32_t t = a.tile_order[blockIdx.x]; tile_y = t / a.tiles_x; tile_x = t - tile_y * a.tiles_x; }
+    const uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y;
     const uint32_t gx = tile_x * 8u + (lane & 7u);
     const uint32_t ty = tile_y * 8u + (lane >> 3);   // tile-local row
     const uint32_t gy = tile_row_to_storage(ty, a.row_begin, a.row_block, a.row_stride);
@@ -352,12 +348,6 @@ static int launch_impl(mc_context* ctx, const mc_mandelbrot_params* p, void* d_r
     if (warm) {   // one tile, a handful of iterations; d_iters holds at least rows x W counts (the caller's scratch)
         grid = dim3(1, 1);
         a.max_iter = p->max_iter < 32u ? p->max_iter : 32u;
-    }
-    a.tiles_x = grid.x;
-    a.tile_order = nullptr;
-    if (!warm && ctx->debug_tile_order && ctx->debug_tile_order_n == (size_t)grid.x * grid.y) {   // experiment (mc_debug_mandelbrot_tile_order)
-        a.tile_order = (const uint32_t*)ctx->debug_tile_order;
-        grid = dim3(grid.x * grid.y, 1);
     }
     if (p->precision == MC_PRECISION_DS) {
         hipLaunchKernelGGL((mandelbrot_kernel<StateDS, 4>), grid, block, 0, s, a);

@@ -57,9 +57,6 @@ struct mc_context {
     int drain_launch_streams();
     // Device status word: a kernel whose scheduler trips one of its loop bounds ORs a bit in instead of spinning
     // (pathtrace_pool.h: bit 1).  Checked — and cleared — by the blocking entry points and mc_context_synchronize().
-    // experiment: a caller-supplied dispatch order for the Mandelbrot tiles (mc_debug_mandelbrot_tile_order; not part of the ABI)
-    const void* debug_tile_order = nullptr;
-    size_t debug_tile_order_n = 0;
     mc::DeviceBuffer status;
     int ensure_status();
     int check_status();   // call after the stream is idle: MC_OK, or MC_ERR_HIP with a detail message

@@ -26,3 +26,7 @@ int launch_careful(const PTArgs& a, int variant, int S, int prec, uint32_t tile_
 }
 }  // namespace pt
 }  // namespace mc
+
+#ifdef MC_PT_REGION_STATS
+namespace mc { namespace pt { MC_PT_REGION_STATS_READER(region_stats_careful) } }   // (summed by mc_debug_pt_region_stats, pathtrace_fast.hip)
+#endif

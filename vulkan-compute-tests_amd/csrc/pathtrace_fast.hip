@@ -35,14 +35,17 @@ int launch_fast(const PTArgs& a, int variant, int S, int prec, uint32_t tile_row
 }  // namespace mc
 
 #ifdef MC_PT_REGION_STATS
-// Diagnostic build (make stats): read and reset the per-region execution / active-lane counters of the fast kernels.
-extern "C" int mc_debug_pt_region_stats(unsigned long long* exec16, unsigned long long* lanes16) {   // (32 entries each)
-    unsigned long long zero[32] = {0};
-    if (hipMemcpyFromSymbol(exec16, HIP_SYMBOL(mc::pt::g_region_exec), sizeof(zero)) != hipSuccess) return 3;
-    if (hipMemcpyFromSymbol(lanes16, HIP_SYMBOL(mc::pt::g_region_lanes), sizeof(zero)) != hipSuccess) return 3;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(mc::pt::g_region_exec), zero, sizeof(zero)) != hipSuccess) return 3;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(mc::pt::g_region_lanes), zero, sizeof(zero)) != hipSuccess) return 3;
-    return 0;
+// Diagnostic build (make stats): read and reset the per-region execution / active-lane counters — of all three tiers' kernels.
+namespace mc { namespace pt {
+MC_PT_REGION_STATS_READER(region_stats_fast)
+int region_stats_careful(unsigned long long*, unsigned long long*);
+int region_stats_strict(unsigned long long*, unsigned long long*);
+} }
+extern "C" int mc_debug_pt_region_stats(unsigned long long* exec32, unsigned long long* lanes32) {   // (32 entries each)
+    for (int i = 0; i < 32; i++) exec32[i] = lanes32[i] = 0;
+    int rc = mc::pt::region_stats_fast(exec32, lanes32);
+    if (!rc) rc = mc::pt::region_stats_careful(exec32, lanes32);
+    if (!rc) rc = mc::pt::region_stats_strict(exec32, lanes32);
+    return rc;
 }
 #endif
-

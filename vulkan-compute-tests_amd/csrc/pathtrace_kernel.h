@@ -184,8 +184,22 @@ static __device__ unsigned long long g_region_lanes[32];
             atomicAdd(&g_region_lanes[r], (unsigned long long)__popcll(m_));                    \
         }                                                                                       \
     } while (0)
+// The counters are per translation unit (fast / careful / strict tier): each defines a reader with this macro, and
+// mc_debug_pt_region_stats (pathtrace_fast.hip) sums the three — a request the host renders with the careful or the strict tier
+// (five or more spheres, an enclosed light, an explicit mode) is counted too.
+#define MC_PT_REGION_STATS_READER(name)                                                                              \
+    int name(unsigned long long* exec32, unsigned long long* lanes32) {                                              \
+        unsigned long long e[32], l[32], zero[32] = {0};                                                             \
+        if (hipMemcpyFromSymbol(e, HIP_SYMBOL(mc::pt::g_region_exec), sizeof(zero)) != hipSuccess) return 3;         \
+        if (hipMemcpyFromSymbol(l, HIP_SYMBOL(mc::pt::g_region_lanes), sizeof(zero)) != hipSuccess) return 3;        \
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mc::pt::g_region_exec), zero, sizeof(zero)) != hipSuccess) return 3;        \
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mc::pt::g_region_lanes), zero, sizeof(zero)) != hipSuccess) return 3;       \
+        for (int i = 0; i < 32; i++) { exec32[i] += e[i]; lanes32[i] += l[i]; }                                      \
+        return 0;                                                                                                    \
+    }
 #else
 #define MC_REGION(r) do { } while (0)
+#define MC_PT_REGION_STATS_READER(name)
 #endif
 
 // Fast mode only: MC_PT_FAST_CONTRACT selects where the compiler may contract a*b+c (pathtrace_fast.hip):

@@ -11,3 +11,7 @@ int launch_strict(const PTArgs& a, int variant, int S, int prec, uint32_t tile_r
 }
 }  // namespace pt
 }  // namespace mc
+
+#ifdef MC_PT_REGION_STATS
+namespace mc { namespace pt { MC_PT_REGION_STATS_READER(region_stats_strict) } }   // (summed by mc_debug_pt_region_stats, pathtrace_fast.hip)
+#endif

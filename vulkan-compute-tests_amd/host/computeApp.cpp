@@ -33,7 +33,6 @@ void ComputeApp::setReferencePng(bool r) {
 
 ComputeApp::~ComputeApp() {
     if (warmThread.joinable()) warmThread.join();
-    if (allocThread.joinable()) allocThread.join();
     // cleanupVulkanResources (vulkanComputeApp.cpp:673-695)
     if (multi) mc_multi_destroy(multi);
     if (ctx) mc_context_destroy(ctx);
@@ -49,9 +48,6 @@ void ComputeApp::check(int status, const char* what) {
 }
 
 void ComputeApp::init() {
-    // The storage buffer first: pinning it needs the HIP runtime, whose start-up the helper thread shares with the calls below, and then
-    // runs beside context creation, warm-up and the render itself (K4: 629 MB, ~90 ms — profiles/r06_cold_timeline.txt).
-    if (overlapStart && storageBytes()) createBuffer(storageBytes());
     int n = 0;
     int rc = mc_device_count(&n);
     if (rc != MC_OK || n == 0) throw std::runtime_error("could not find a device with HIP support");   // cf. vulkanComputeApp.cpp:78
@@ -98,31 +94,16 @@ void HostStorage::allocate(uint64_t bytes) {
 }
 
 void ComputeApp::createBuffer(uint64_t bufferSizeBytes) {
-    auto t0 = std::chrono::steady_clock::now();
-    HostStorage& target = gpuPostprocess ? rgba8 : buffer;
-    const uint64_t bytes = gpuPostprocess ? bufferSizeBytes / 4 : bufferSizeBytes;   // 16 B/pixel of fp32 -> 4 B/pixel of RGBA8
-    if (!overlapStart) {
-        target.allocate(bytes);
-        times.allocMs += msSince(t0);
-        return;
-    }
-    if (allocStartedFor == bytes) return;            // init() started exactly this allocation already
-    waitStorage();                                   // (another size was in flight: finish it, then replace it)
-    allocStartedFor = bytes;
-    allocThread = std::thread([this, &target, bytes] {
-        auto t1 = std::chrono::steady_clock::now();
-        try { target.allocate(bytes); } catch (const std::exception& e) { allocError = e.what(); }
-        times.allocThreadMs = msSince(t1);
-    });
-    times.allocMs += msSince(t0);
+    deferredAlloc = gpuPostprocess ? bufferSizeBytes / 4 : bufferSizeBytes;   // 16 B/pixel of fp32 -> 4 B/pixel of RGBA8
+    if (!overlapStart) ensureStorage();   // (else: after the render has been launched — runCommandBuffer)
 }
 
-void ComputeApp::waitStorage() {
-    if (!allocThread.joinable()) return;
+void ComputeApp::ensureStorage() {
+    if (!deferredAlloc) return;
     auto t0 = std::chrono::steady_clock::now();
-    allocThread.join();
+    (gpuPostprocess ? rgba8 : buffer).allocate(deferredAlloc);
+    deferredAlloc = 0;
     times.allocMs += msSince(t0);
-    if (!allocError.empty()) { std::string e = allocError; allocError.clear(); allocStartedFor = 0; throw std::runtime_error(e); }
 }
 
 void ComputeApp::convertStorage(std::vector<uint8_t>& image, uint32_t resx, uint32_t resy, float scale, bool rotate180) const {
@@ -136,7 +117,7 @@ void ComputeApp::run() {
     auto t0 = std::chrono::steady_clock::now();
     waitWarmup();
     runCommandBuffer();
-    waitStorage();   // (every runCommandBuffer joins it before its copy; this covers one that had nothing to copy)
+    ensureStorage();   // (every runCommandBuffer allocates before its copy; this covers one that had nothing to copy)
     auto t1 = std::chrono::steady_clock::now();
     lastRunMs = std::chrono::duration<double, std::milli>(t1 - t0).count();
     times.runMs = lastRunMs;

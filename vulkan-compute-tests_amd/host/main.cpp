@@ -70,7 +70,7 @@ int main(int argc, char* argv[]) {
             mathMode = choice(argv[++i], {{"strict", MC_PT_MATH_STRICT}, {"fast", MC_PT_MATH_FAST}, {"careful", MC_PT_MATH_FAST_CAREFUL}});
         }
         else if (a == "--reference-png") referencePng = true;       // the reference's lodepng::encode (make REFERENCE=<checkout>)
-        else if (a == "--serial-start") overlapStart = false;        // measurements: the round-5 start-up order (no helper threads)
+        else if (a == "--serial-start") overlapStart = false;        // measurements: the round-5 start-up order (allocate in preRun, no warm-up)
         else if (a == "--large-sphere-walls") largeSpheres = true;   // TEST_PRECISION_WITH_LARGE_SPHERE_WALLS (pathtracerApp.h:11)
         else if (a == "--sphere-precision") {                        // which #if branch of pathTracer.comp:132-256 is active
             need(1);
@@ -126,12 +126,12 @@ int main(int argc, char* argv[]) {
                             // which kernel + copy are device time; convert = float -> u8 (+ rotation) on the host (0: done on the device);
                             // png = encode + write; total = process wall time up to here
             const ComputeApp::Timing& t = app.timing();
-            // (alloc = what the calling thread spent on / waiting for the storage buffer; alloc_thread, warmup = the helper threads'
-            //  own durations, warmup_wait = what run() still waited for the warm-up: overlapped start-up, computeApp.h)
+            // (alloc = the storage buffer — inside run(), while the device renders, unless --serial-start; warmup = the warm-up call on
+            //  its helper thread, warmup_wait = what run() still waited for it: computeApp.h)
             printf("{\"timing_ms\": {\"init\": %.3f, \"alloc\": %.3f, \"run\": %.3f, \"kernel\": %.3f, \"copy\": %.3f, \"convert\": %.3f, "
-                   "\"png\": %.3f, \"total\": %.3f, \"alloc_thread\": %.3f, \"warmup\": %.3f, \"warmup_wait\": %.3f}, "
+                   "\"png\": %.3f, \"total\": %.3f, \"warmup\": %.3f, \"warmup_wait\": %.3f}, "
                    "\"gpu_postprocess\": %s, \"gpus\": %d, \"overlap_start\": %s, \"reference_png\": %s}\n",
-                   initMs, t.allocMs, t.runMs, t.kernelMs, t.copyMs, t.convertMs, t.pngMs, since(tStart), t.allocThreadMs, t.warmupMs,
+                   initMs, t.allocMs, t.runMs, t.kernelMs, t.copyMs, t.convertMs, t.pngMs, since(tStart), t.warmupMs,
                    t.warmupWaitMs, gpuPost ? "true" : "false", gpus, overlapStart ? "true" : "false", referencePng ? "true" : "false");
         }
     } catch (const std::runtime_error& e) {

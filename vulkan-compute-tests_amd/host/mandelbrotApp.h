@@ -40,7 +40,6 @@ struct MandelbrotApp : public ComputeApp {
         params.row_begin = 0; params.row_end = resy;
     }
 
-    virtual uint64_t storageBytes() const override { return bufferSize; }
     virtual int warmup() override {   // helper thread of init(): tables + code object of the request run() will make
         mc_mandelbrot_params q = params;
         q.k_color[0] = 0.1f; q.k_color[1] = 0.7f; q.k_color[2] = 0.6f; q.k_color[3] = 0.0f;   // as createCommandBuffer sets it
@@ -48,17 +47,17 @@ struct MandelbrotApp : public ComputeApp {
         return mc_context_warmup_mandelbrot(ctx, &q, gpuPostprocess ? 1 : 0);
     }
 
-    // gpuPostprocess: render + float->u8 on the device, 4 B/pixel cross PCIe instead of 16.  One GPU: launch, THEN wait for the
-    // storage buffer (allocated on a helper thread since init(): K4's 629 MB take longer to pin than its render takes), then copy.
+    // gpuPostprocess: render + float->u8 on the device, 4 B/pixel cross PCIe instead of 16.  One GPU: launch, THEN allocate the
+    // storage buffer (while the device renders; mc_host_alloc: K4's 629 MB in 4 ms), then copy.
     virtual void runCommandBuffer() override {
         if (multi) {
-            waitStorage();
+            ensureStorage();
             if (gpuPostprocess) check(mc_multi_mandelbrot_render_rgba8(multi, &params, rgba8.bytes()), "mc_multi_mandelbrot_render_rgba8");
             else check(mc_multi_mandelbrot_render(multi, &params, buffer.data(), nullptr), "mc_multi_mandelbrot_render");
             return;
         }
         check(mc_mandelbrot_render_begin(ctx, &params, gpuPostprocess ? 1 : 0), "mc_mandelbrot_render_begin");
-        waitStorage();
+        ensureStorage();
         if (gpuPostprocess) check(mc_render_end(ctx, rgba8.bytes(), rgba8.sizeBytes()), "mc_render_end");
         else check(mc_render_end(ctx, buffer.data(), buffer.sizeBytes()), "mc_render_end");
     }

@@ -79,7 +79,6 @@ struct PathtracerApp : public ComputeApp {
         params.row_begin = 0; params.row_end = resy;
     }
 
-    virtual uint64_t storageBytes() const override { return bufferSize; }
     virtual int warmup() override {   // helper thread of init(): what run() is going to ask for (the setters were called before init())
         mc_pathtrace_params q = params;
         q.width = resx; q.height = resy; q.spp = (uint32_t)spp; q.sample_begin = 0; q.sample_end = q.spp; q.row_begin = 0; q.row_end = resy;
@@ -88,11 +87,11 @@ struct PathtracerApp : public ComputeApp {
     }
 
     // gpuPostprocess: render + float->u8 + 180-degree rotation on the device (pathtracerApp.h:202-243), 4 B/pixel copied.
-    // One GPU: launch, THEN wait for the storage buffer (its allocation runs on a helper thread since init()), then copy.
+    // One GPU: launch, THEN allocate the storage buffer (while the device renders), then copy.
     virtual void runCommandBuffer() override {
         const uint32_t np = (uint32_t)planes.size() / 12, ns = (uint32_t)spheres.size() / 12;
         if (multi) {
-            waitStorage();
+            ensureStorage();
             if (gpuPostprocess) check(mc_multi_pathtrace_render_rgba8(multi, &params, planes.data(), np, spheres.data(), ns, rgba8.bytes()),
                                       "mc_multi_pathtrace_render_rgba8");
             else check(mc_multi_pathtrace_render(multi, &params, planes.data(), np, spheres.data(), ns, buffer.data()),
@@ -101,7 +100,7 @@ struct PathtracerApp : public ComputeApp {
         }
         check(mc_pathtrace_render_begin(ctx, &params, planes.data(), np, spheres.data(), ns, gpuPostprocess ? 1 : 0),
               "mc_pathtrace_render_begin");
-        waitStorage();
+        ensureStorage();
         if (gpuPostprocess) check(mc_render_end(ctx, rgba8.bytes(), rgba8.sizeBytes()), "mc_render_end");
         else check(mc_render_end(ctx, buffer.data(), buffer.sizeBytes()), "mc_render_end");
     }
