@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-/* 2 (round 6): + mc_assemble_rgba8_device_async, mc_context_warmup_*, mc_*_render_begin / mc_render_end; since 1 (round 5 additions, un-bumped then): mc_build_id,
+/* 2 (round 6): + mc_assemble_rgba8_device_async, mc_context_warmup_*; since 1 (round 5 additions, un-bumped then): mc_build_id,
  * mc_host_alloc / mc_host_free, mc_context_last_timing, math_mode 2, scene-class bit 16; the measurement flag enums moved to
  * mc_compute_test.h.  A binder checks mc_abi_version() against the MC_ABI_VERSION it was written for. */
 #define MC_ABI_VERSION 2
@@ -208,24 +208,13 @@ int mc_pathtrace_render_rgba8(mc_context* ctx, const mc_pathtrace_params* p, con
  * RGBA8 image when rgba8 != 0), timing events, scene / colour / c tables, and a 16 x 8 (one-tile) launch of the kernel family the
  * request selects, so that the code object is resident.  Blocks the CALLING thread for the load and returns with the tiny launch
  * queued on the context's stream; results are unaffected (the scratch it touches is overwritten by the render).  An application calls
- * it from a helper thread while it does other start-up work, and joins that thread before its next call on the context (a context
- * is not thread-safe). */
+ * it from a helper thread while it does other start-up work (allocating its storage buffer, opening its output), and joins that
+ * thread before its next call on the context (a context is not thread-safe).  (Round 6 also tried to move the storage buffer's
+ * allocation BEHIND the launch with a two-phase render call: registering host memory while a kernel runs stalls the device — K4's
+ * kernel 82 ms instead of 60 — so the buffer is made first, in 4 ms, and the blocking calls stayed as they were.) */
 int mc_context_warmup_pathtrace(mc_context* ctx, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
                                 const float* spheres, uint32_t n_spheres, int rgba8);
 int mc_context_warmup_mandelbrot(mc_context* ctx, const mc_mandelbrot_params* p, int rgba8);
-
-/* Two-phase form of the blocking host-buffer calls.  The kernels write HBM; the application's host buffer is needed only by the
- * final copy — unlike the reference, whose shader writes the mapped host-visible buffer directly and must therefore allocate it first
- * (vulkanComputeApp.cpp:489-533 in preRun, before the dispatch of :451-466).  mc_*_render_begin launches the render (rgba8 != 0: and
- * the conversion of mc_*_render_rgba8) and returns at once; mc_render_end copies the result — (row_end-row_begin)*width*16 bytes, or
- * width*height*4 for rgba8 — to out_host and blocks until it is there.  out_bytes must be exactly that size.  An application can
- * therefore allocate (pin, page in) its storage buffer WHILE the device renders.  Same results, same timing record
- * (mc_context_last_timing), same errors as mc_mandelbrot_render(out_iters = NULL) / mc_pathtrace_render / mc_*_render_rgba8; the
- * path tracer's form renders from sample 0 (a progressive continuation uploads the caller's accumulator: the blocking call). */
-int mc_mandelbrot_render_begin(mc_context* ctx, const mc_mandelbrot_params* p, int rgba8);
-int mc_pathtrace_render_begin(mc_context* ctx, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
-                              const float* spheres, uint32_t n_spheres, int rgba8);
-int mc_render_end(mc_context* ctx, void* out_host, size_t out_bytes);
 
 /* Host-side analysis the path tracer applies to a scene before choosing a kernel; touches no device, usable without a
  * GPU.  *out_class: bit 0 (MC_PT_SCENE_SLAB) — six axis-aligned planes in index order x,x,y,y,z,z plus one to eight spheres
@@ -241,7 +230,8 @@ int mc_render_end(mc_context* ctx, void* out_host, size_t out_bytes);
  * often than its tolerance allows: an MC_PT_MATH_FAST request for such a scene is RENDERED WITH THE STRICT KERNELS
  * (bit-identical to the oracle), never silently outside the bound.  Bit 4 (MC_PT_SCENE_MANY_SPHERES) — any scene: five or more spheres.
  * The share of fast-math samples that take another path than the reference's grows with the number of (specular) spheres a path can
- * run through; the fast tier holds the bound with margin up to four and crosses it at six (profiles/r05_fork_census_careful.txt): an
+ * run through; the fast tier holds the bound with margin up to four, reads 3.2 of 4.0 at five and exceeds it from six on (4.4 .. 5.6;
+ * profiles/r05_fork_census_careful.txt) — the switch is at FIVE, one sphere before the bound is crossed: an
  * MC_PT_MATH_FAST request for such a scene is rendered by the careful tier (MC_PT_MATH_FAST_CAREFUL). */
 #define MC_PT_SCENE_SLAB 1u
 #define MC_PT_SCENE_LIGHTS_INSIDE 2u

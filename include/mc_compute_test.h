@@ -30,8 +30,9 @@ enum {
     MC_PT_SCENE_IN_LDS = 1u << 4,   /* generic scenes: every block stages the object records into LDS (the automatic choice   */
     MC_PT_SCENE_IN_MEMORY = 1u << 5,/* for small scenes) / the kernel reads them where they lie (large scenes); strict math:  */
                                     /* bit-identical either way                                                             */
-    MC_PT_NO_FAST_GUARD = 1u << 6   /* run MC_PT_MATH_FAST even on a scene the host classifies as outside the fast tolerance   */
-                                    /* (MC_PT_SCENE_LIGHT_ENCLOSED), which is otherwise rendered strict                   */
+    MC_PT_NO_FAST_GUARD = 1u << 6   /* run the fast TIER (tier 1) of MC_PT_MATH_FAST whatever the host's scene class says: neither     */
+                                    /* the promotion to strict (MC_PT_SCENE_LIGHT_ENCLOSED) nor the promotion to the careful tier      */
+                                    /* (MC_PT_SCENE_MANY_SPHERES: five or more spheres) is applied — this is how tools force "tier 1"  */
 };
 #define MC_PT_FORCE_S(s) ((uint32_t)(s) << 8) /* force the sample-parallel width: 1, 4 or 16 (0 = automatic) */
 

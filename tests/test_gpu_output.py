@@ -193,17 +193,16 @@ def test_pinned_and_pageable_callers_get_identical_bytes_at_the_pinned_rate(ctx,
             fresh.last_timing()
 
 
-def test_two_phase_calls_and_warmup_equal_the_blocking_calls(B, O):
-    """Round 6: mc_context_warmup_* + mc_*_render_begin / mc_render_end — what the apps use to hide the cold start
-    and the pinned allocation — return exactly what the blocking calls return: the fp32 storage buffer and the RGBA8 image, Mandelbrot
-    (fp32 and two-float) and path tracer (strict and fast), on a FRESH context whose first call is the warm-up; argument errors."""
+def test_warmup_leaves_the_blocking_calls_results_unchanged(B, O):
+    """Round 6: mc_context_warmup_* — what the apps call from a helper thread in init() so that run()'s first launch
+    does not pay for the code object, the tables and the device scratch — changes no result: on a FRESH context whose first call is the
+    warm-up, the blocking calls return exactly what they return on a context that was never warmed: the fp32 storage buffer and the
+    RGBA8 image, Mandelbrot (fp32 and two-float; the warm-up builds the REAL colour / c tables and runs one short tile) and path tracer
+    (strict, fast, careful; odd width); argument errors."""
     L = B.lib()
     vp, u32 = C.c_void_p, C.c_uint32
     L.mc_context_warmup_pathtrace.argtypes = [vp, C.POINTER(B.PathtraceParams), vp, u32, vp, u32, C.c_int]
     L.mc_context_warmup_mandelbrot.argtypes = [vp, C.POINTER(B.MandelbrotParams), C.c_int]
-    L.mc_pathtrace_render_begin.argtypes = [vp, C.POINTER(B.PathtraceParams), vp, u32, vp, u32, C.c_int]
-    L.mc_mandelbrot_render_begin.argtypes = [vp, C.POINTER(B.MandelbrotParams), C.c_int]
-    L.mc_render_end.argtypes = [vp, vp, C.c_size_t]
     L.mc_pathtrace_render_rgba8.argtypes = [vp, C.POINTER(B.PathtraceParams), vp, u32, vp, u32, vp]
     L.mc_mandelbrot_render_rgba8.argtypes = [vp, C.POINTER(B.MandelbrotParams), vp]
     planes, spheres = B.default_scene()
@@ -213,7 +212,7 @@ def test_two_phase_calls_and_warmup_equal_the_blocking_calls(B, O):
         return a.ctypes.data_as(vp)
 
     with B.Context(0) as ref_ctx:
-        for mode in (B.PT_MATH_STRICT, B.PT_MATH_FAST):
+        for mode in (B.PT_MATH_STRICT, B.PT_MATH_FAST, B.PT_MATH_FAST_CAREFUL):
             for W, H in ((96, 64), (51, 30)):
                 q = B.pathtrace_params(W, H, 12, math_mode=mode)
                 want = ref_ctx.pathtrace(q)
@@ -222,45 +221,36 @@ def test_two_phase_calls_and_warmup_equal_the_blocking_calls(B, O):
                 for rgba8 in (0, 1):
                     with B.Context(0) as c:                       # fresh: the warm-up is this context's first launch
                         assert L.mc_context_warmup_pathtrace(c._h, C.byref(q), pl, 6, sp, 3, rgba8) == 0
-                        assert L.mc_pathtrace_render_begin(c._h, C.byref(q), pl, 6, sp, 3, rgba8) == 0
-                        got = np.zeros((H, W, 4), np.uint8 if rgba8 else np.float32)
-                        assert L.mc_render_end(c._h, ptr(got), got.nbytes - 4) == 1          # wrong size: refused, still pending
-                        assert L.mc_render_end(c._h, ptr(got), got.nbytes) == 0
-                        assert L.mc_render_end(c._h, ptr(got), got.nbytes) == 1              # nothing pending any more
-                        k, cp = c.last_timing()
-                        assert k > 0 and cp > 0
                         if rgba8:
+                            got = np.zeros((H, W, 4), np.uint8)
+                            assert L.mc_pathtrace_render_rgba8(c._h, C.byref(q), pl, 6, sp, 3, ptr(got)) == 0
                             assert np.array_equal(got, want8)
                         else:
-                            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
-        # a tile (interleaved rows) through the two-phase form; a continuation is refused there
+                            assert np.array_equal(c.pathtrace(q).view(np.uint32), want.view(np.uint32))
+                        k, cp = c.last_timing()
+                        assert k > 0 and cp > 0
+        # a tile request warms up too (its scratch is the tile's); a request the render would refuse is refused by the warm-up
         q = B.pathtrace_params(64, 48, 6, row_begin=8, row_end=48, row_block=8, row_stride=16)
         want = ref_ctx.pathtrace(q)
         with B.Context(0) as c:
-            assert L.mc_pathtrace_render_begin(c._h, C.byref(q), pl, 6, sp, 3, 0) == 0
-            got = np.zeros_like(want)
-            assert L.mc_render_end(c._h, ptr(got), got.nbytes) == 0 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
-            assert L.mc_pathtrace_render_begin(c._h, C.byref(q), pl, 6, sp, 3, 1) == 1       # RGBA8: whole, finished images only
-            q2 = B.pathtrace_params(64, 48, 6, sample_begin=2)
-            assert L.mc_pathtrace_render_begin(c._h, C.byref(q2), pl, 6, sp, 3, 0) == 1
-        # Mandelbrot, fp32 and two-float (the warm-up builds the REAL colour / c tables, then runs one short tile)
+            assert L.mc_context_warmup_pathtrace(c._h, C.byref(q), pl, 6, sp, 3, 0) == 0
+            assert np.array_equal(c.pathtrace(q).view(np.uint32), want.view(np.uint32))
+            bad = B.pathtrace_params(64, 48, 6, row_begin=40, row_end=60)
+            assert L.mc_context_warmup_pathtrace(c._h, C.byref(bad), pl, 6, sp, 3, 0) == 1
         for kw in (dict(max_iter=300), dict(max_iter=700, precision=B.PRECISION_DS, centre=(-0.7436438870371587, 0.13182590420531198),
                                             scale=(1e-6, 1e-6))):
             p = B.mandelbrot_params(200, 121, **kw)
-            want, _ = ref_ctx.mandelbrot(p, want_iters=False)
+            want, want_it = ref_ctx.mandelbrot(p)
             want8 = np.empty((121, 200, 4), np.uint8)
             assert L.mc_mandelbrot_render_rgba8(ref_ctx._h, C.byref(p), ptr(want8)) == 0
             for rgba8 in (0, 1):
                 with B.Context(0) as c:
                     assert L.mc_context_warmup_mandelbrot(c._h, C.byref(p), rgba8) == 0
-                    assert L.mc_mandelbrot_render_begin(c._h, C.byref(p), rgba8) == 0
-                    got = np.zeros((121, 200, 4), np.uint8 if rgba8 else np.float32)
-                    assert L.mc_render_end(c._h, ptr(got), got.nbytes) == 0
-                    assert np.array_equal(got, want8) if rgba8 else np.array_equal(got.view(np.uint32), want.view(np.uint32))
-                    # the blocking call on a warmed context: unchanged, iteration plane included
                     rg, it = c.mandelbrot(p)
-                    assert np.array_equal(rg.view(np.uint32), want.view(np.uint32))
-        assert L.mc_render_end(None, ptr(want8), 4) == 1 and L.mc_context_warmup_mandelbrot(None, C.byref(p), 0) == 1
+                    assert np.array_equal(rg.view(np.uint32), want.view(np.uint32)) and np.array_equal(it, want_it)
+                    got = np.zeros((121, 200, 4), np.uint8)
+                    assert L.mc_mandelbrot_render_rgba8(c._h, C.byref(p), ptr(got)) == 0 and np.array_equal(got, want8)
+        assert L.mc_context_warmup_mandelbrot(None, C.byref(p), 0) == 1 and L.mc_context_warmup_pathtrace(None, C.byref(q), pl, 6, sp, 3, 0) == 1
 
 
 def test_apps_overlapped_start_writes_the_same_file_as_the_serial_start(B, tmp_path):

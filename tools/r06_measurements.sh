@@ -1,0 +1,43 @@
+#!/bin/bash
+# Every GPU measurement of round 6, as it was run through gpurun (one or more sections per call; records under profiles/r06_*).
+#   bash tools/r06_measurements.sh <section> [<section> ...]
+set -o pipefail
+cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; out=gpurun_out; mkdir -p $out
+for section in "$@"; do
+case "$section" in
+timeline)   # where a cold process spends its first 100 ms, what overlaps (tools/cold_timeline.cpp)        -> profiles/r06_cold_timeline.txt
+  for m in seq alloc warm both seq both; do tools/bin/cold_timeline $m; done > $out/r06_cold_timeline.txt 2>&1 || exit 1 ;;
+hostmem)    # the storage buffer's host side: hipHostMalloc / huge pages + parallel touch + register / pageable -> profiles/r06_hostmem_probe.txt
+  timeout -k 10 300 tools/bin/cold_timeline hostmem > $out/r06_hostmem_probe.txt 2>&1 || exit 1 ;;
+wall)       # process wall time with RCCL loaded on demand / preloaded (the rounds 1-5 link line)           -> profiles/r06_process_wall.txt
+  timeout -k 10 300 python tools/process_wall.py > $out/r06_process_wall.txt 2>&1 || exit 1 ;;
+e2e)        # the apps as cold processes, overlapped start against --serial-start, both routes, K2 / K1 / K4 -> profiles/r06_end_to_end.txt
+  timeout -k 10 900 python tools/end_to_end.py > $out/r06_end_to_end.txt 2>&1 || exit 1 ;;
+bench)      # bench.py's default line (with end_to_end, app_default, cpu_baseline)                          -> profiles/r06_bench_k2.json
+  python bench.py > $out/r06_bench_k2.json 2> $out/r06_bench_k2.err || { tail -5 $out/r06_bench_k2.err; exit 1; } ;;
+benchall)   # the other configurations on one GPU                                                           -> profiles/r06_bench_others.jsonl
+  : > $out/r06_bench_others.jsonl; for c in K1 K1ds K3 K4; do python bench.py --config $c >> $out/r06_bench_others.jsonl 2>> $out/r06_bench_others.err || exit 1; done &&
+  python bench.py --math strict --no-secondary --no-end-to-end >> $out/r06_bench_others.jsonl 2>> $out/r06_bench_others.err &&
+  python bench.py --math careful --no-secondary --no-end-to-end --no-cpu-baseline >> $out/r06_bench_others.jsonl 2>> $out/r06_bench_others.err ;;
+rehearsal)  # the driver's PLAIN multi-GPU command, 2 / 4 / 8 ranks sharing the one GPU (gloo: timings are not measurements): the `multi`
+            # block with K3 and K4 at full size, per-rank evidence, bit-equality, retention                   -> profiles/r06_rehearsal_plain.jsonl
+  : > $out/r06_rehearsal_plain.jsonl
+  for n in 2 4; do MC_BENCH_BACKEND=gloo timeout -k 10 600 python bench.py --gpus $n >> $out/r06_rehearsal_plain.jsonl 2>> $out/r06_rehearsal_plain.err || { tail -5 $out/r06_rehearsal_plain.err; exit 1; }; done ;;
+profile)    # the rocprofv3 evidence behind bench.py's K2 lines, stamped with the build id                  -> profiles/r06_pt_{fast,strict}_*
+  bash tools/profile_gpu.sh r06_pt_fast --no-end-to-end > $out/r06_profile_fast.log 2>&1 && python tools/summarize_prof.py r06_pt_fast $out/r06_pt_fast > /dev/null &&
+  bash tools/profile_gpu.sh r06_pt_strict --math strict --no-end-to-end > $out/r06_profile_strict.log 2>&1 && python tools/summarize_prof.py r06_pt_strict $out/r06_pt_strict > /dev/null ;;
+profile2)   # K1 / K1ds / K4 on the round-6 build                                                           -> profiles/r06_{mandel,mandel_ds,k4}_*
+  bash tools/profile_gpu.sh r06_mandel --config K1 > $out/r06_profile_mandel.log 2>&1 && python tools/summarize_prof.py r06_mandel $out/r06_mandel > /dev/null &&
+  bash tools/profile_gpu.sh r06_mandel_ds --config K1ds > $out/r06_profile_mandel_ds.log 2>&1 && python tools/summarize_prof.py r06_mandel_ds $out/r06_mandel_ds > /dev/null &&
+  bash tools/profile_gpu.sh r06_k4 --config K4 --steps 2 > $out/r06_profile_k4.log 2>&1 && python tools/summarize_prof.py r06_k4 $out/r06_k4 > /dev/null ;;
+profile3)   # K3's launch (3840 x 2560 x 4096 spp, 2 s) under the counters                                   -> profiles/r06_k3_*
+  bash tools/profile_gpu.sh r06_k3 --config K3 --steps 1 --warmup 1 > $out/r06_profile_k3.log 2>&1 && python tools/summarize_prof.py r06_k3 $out/r06_k3 > /dev/null ;;
+fuzz)       # randomised campaigns on the final build                                                       -> profiles/r06_fuzz_*.log
+  timeout -k 10 330 python tools/fuzz_parity.py --seconds 240 --seed 61 > $out/r06_fuzz_parity.log 2>&1; r1=$?
+  timeout -k 10 330 python tools/fuzz_fast.py --seconds 240 --seed 62 --enclose --many > $out/r06_fuzz_fast.log 2>&1; r2=$?
+  tail -2 $out/r06_fuzz_parity.log $out/r06_fuzz_fast.log; [ $r1 -eq 0 ] && [ $r2 -eq 0 ] || exit 1 ;;
+tests)
+  timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $out/r06_gputest.log 2>&1; rc=$?; tail -5 $out/r06_gputest.log; [ $rc -eq 0 ] || exit $rc ;;
+*) echo "usage: $0 <section> ..."; exit 2 ;;
+esac
+done

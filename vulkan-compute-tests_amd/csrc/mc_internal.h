@@ -65,9 +65,6 @@ struct mc_context {
     hipEvent_t t_ev[3] = {nullptr, nullptr, nullptr};
     bool timing_valid = false;
     int mark(int k);      // records t_ev[k] on the context's stream (creating the events on first use)
-    // Two-phase host-buffer calls (mc_*_render_begin ... mc_render_end): what the pending render left in scratch for the copy.
-    const void* pending_src = nullptr;
-    size_t pending_bytes = 0;
 };
 
 namespace mc {

@@ -245,7 +245,8 @@ int pathtrace_plan(const mc_pathtrace_params* p, const float* planes, uint32_t n
     }
     // Fast math never runs where it cannot hold its tolerance: a scene with a light all but enclosed by an opaque sphere
     // (light_nearly_enclosed) is rendered strict; a scene with kCarefulSpheres or more spheres by the careful tier (pathtrace_careful.hip:
-    // the share of samples that fork grows with the sphere count, and the fast tier's 99.9-percentile crosses the bound at six).
+    // the share of samples that fork grows with the sphere count; the fast tier's 99.9-percentile reads 3.2 of 4.0 at five spheres and exceeds
+    // the bound from six on — the switch sits one sphere before the crossing).
     plan.math_mode = p->math_mode;
     if (p->math_mode != MC_PT_MATH_STRICT && !(p->flags & MC_PT_NO_FAST_GUARD)) {
         if (light_nearly_enclosed(spheres, n_spheres)) plan.math_mode = MC_PT_MATH_STRICT;

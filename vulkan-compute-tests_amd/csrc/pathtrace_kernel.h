@@ -748,7 +748,10 @@ template <int Fast> __device__ __forceinline__ v3 specular_bounce_fast(int mat, 
         }
     }
     const v3 out = rd * alpha + n * beta;
-    if constexpr (Fast == 2 || MC_PT_FAST_RENORMALISE != 0) return normalize<Fast>(out);   // (:441 normalises the refracted ray)
+    // Careful tier: ONE direction is formed for all three outcomes, so the re-normalisation applies to all of them — the refracted ray,
+    // which the reference normalises (:441), and the two reflections (:433, :446), which it leaves as reflect() returns them (unit to
+    // within a rounding for unit rd and n: the extra normalize moves them by an ulp or so, inside the tier's tolerance).
+    if constexpr (Fast == 2 || MC_PT_FAST_RENORMALISE != 0) return normalize<Fast>(out);
     return out;
 }
 

@@ -94,16 +94,14 @@ void HostStorage::allocate(uint64_t bytes) {
 }
 
 void ComputeApp::createBuffer(uint64_t bufferSizeBytes) {
-    deferredAlloc = gpuPostprocess ? bufferSizeBytes / 4 : bufferSizeBytes;   // 16 B/pixel of fp32 -> 4 B/pixel of RGBA8
-    if (!overlapStart) ensureStorage();   // (else: after the render has been launched — runCommandBuffer)
-}
-
-void ComputeApp::ensureStorage() {
-    if (!deferredAlloc) return;
+    // In preRun(), where the reference allocates (vulkanComputeApp.cpp:489-533) — and BEFORE the render is launched: registering 629 MB
+    // with the runtime while a kernel runs (tried in round 6: allocate between mc_*_render_begin and mc_render_end) stalls the device —
+    // K4's kernel read 82 ms instead of 60 and the copy that followed 38 GB/s instead of 57 (profiles/r06_end_to_end.txt, first table).
+    // mc_host_alloc makes the buffer in 4 ms; there is nothing left to hide.
     auto t0 = std::chrono::steady_clock::now();
-    (gpuPostprocess ? rgba8 : buffer).allocate(deferredAlloc);
-    deferredAlloc = 0;
-    times.allocMs += msSince(t0);
+    if (gpuPostprocess) rgba8.allocate(bufferSizeBytes / 4);   // 16 B/pixel of fp32 -> 4 B/pixel of RGBA8
+    else buffer.allocate(bufferSizeBytes);
+    times.allocMs = msSince(t0);
 }
 
 void ComputeApp::convertStorage(std::vector<uint8_t>& image, uint32_t resx, uint32_t resy, float scale, bool rotate180) const {
@@ -117,7 +115,6 @@ void ComputeApp::run() {
     auto t0 = std::chrono::steady_clock::now();
     waitWarmup();
     runCommandBuffer();
-    ensureStorage();   // (every runCommandBuffer allocates before its copy; this covers one that had nothing to copy)
     auto t1 = std::chrono::steady_clock::now();
     lastRunMs = std::chrono::duration<double, std::milli>(t1 - t0).count();
     times.runMs = lastRunMs;

@@ -75,10 +75,9 @@ struct ComputeApp {
     static bool referencePngAvailable();
     // Cold-start hiding, on by default, switchable for measurements:
     //   overlapStart   init() hands mc_context_warmup_* to a helper thread as soon as the context exists (joined before run() touches
-    //                  the context): the kernel family's code object, tables and device scratch are ready when run() launches; and
-    //                  the storage buffer is allocated AFTER the render has been launched (mc_*_render_begin), not in preRun(): the
-    //                  kernels write HBM, the host buffer is needed only by the copy (mc_render_end), so its allocation costs nothing;
-    //   false          the round-5 order: allocate in preRun() as the reference does, first launch inside run().
+    //                  the context): the kernel family's code object, tables and device scratch are ready when run() launches, and
+    //                  the helper works while the caller allocates its storage buffer in preRun();
+    //   false          the round-5 order: the first launch, with everything it drags in, inside run().
     void setOverlapStart(bool o) { overlapStart = o; }
     // saveRenderedImage's file: a standard PNG of exactly the RGBA8 pixels the reference converts its buffer to (mandelbrotApp.h:159-174,
     // pathtracerApp.h:202-243), deflated stripe-parallel by pngWriter.h.  The reference encodes the same pixels with its vendored
@@ -89,16 +88,14 @@ struct ComputeApp {
     // Where the time of the last run() / saveRenderedImage() went (milliseconds; SURVEY §8d "end-to-end ... reported separately"):
     // device time of the kernels and of the device -> host copy (mc_context_last_timing; 0 for multi-GPU runs), the host
     // float -> u8 (+ rotation) loop, the PNG encoder + file write.
-    // allocMs = the storage buffer's allocation (overlapStart: inside run(), while the device renders); warmupMs = the warm-up call
-    // on its helper thread, warmupWaitMs = what run() still waited for it.
+    // allocMs = the storage buffer's allocation (preRun()); warmupMs = the warm-up call on its helper thread, warmupWaitMs = what
+    // run() still waited for it.
     struct Timing { double allocMs = 0, runMs = 0, kernelMs = 0, copyMs = 0, convertMs = 0, pngMs = 0, warmupMs = 0, warmupWaitMs = 0; };
     const Timing& timing() const { return times; }
 
 protected:
     void createBuffer(uint64_t bufferSizeBytes);   // vulkanComputeApp.cpp:489-533: the output storage buffer (gpuPostprocess: a quarter
-                                                   // of it, for the RGBA8 image).  With overlapStart only noted here and carried
-                                                   // out by ensureStorage()
-    void ensureStorage();                          // before the first use of buffer / rgba8: the allocation createBuffer deferred
+                                                   // of it, for the RGBA8 image)
     void waitWarmup();                             // before the first call on ctx after init(): joins the warm-up helper
     virtual int warmup() { return MC_OK; }                // apps: mc_context_warmup_* for the request run() will make (helper thread)
     static void check(int status, const char* what);
@@ -113,7 +110,6 @@ protected:
     bool referencePng = false;
     bool overlapStart = true;
     std::thread warmThread;
-    uint64_t deferredAlloc = 0;     // bytes createBuffer noted for ensureStorage() (0: nothing pending)
     int warmStatus = MC_OK;
     std::string warmError;
     HostStorage rgba8;            // gpuPostprocess: the RGBA8 image run() fills (page-locked too: 4 B/pixel cross PCIe), allocated by

@@ -70,7 +70,7 @@ int main(int argc, char* argv[]) {
             mathMode = choice(argv[++i], {{"strict", MC_PT_MATH_STRICT}, {"fast", MC_PT_MATH_FAST}, {"careful", MC_PT_MATH_FAST_CAREFUL}});
         }
         else if (a == "--reference-png") referencePng = true;       // the reference's lodepng::encode (make REFERENCE=<checkout>)
-        else if (a == "--serial-start") overlapStart = false;        // measurements: the round-5 start-up order (allocate in preRun, no warm-up)
+        else if (a == "--serial-start") overlapStart = false;        // measurements: the round-5 start-up order (no warm-up thread)
         else if (a == "--large-sphere-walls") largeSpheres = true;   // TEST_PRECISION_WITH_LARGE_SPHERE_WALLS (pathtracerApp.h:11)
         else if (a == "--sphere-precision") {                        // which #if branch of pathTracer.comp:132-256 is active
             need(1);
@@ -126,8 +126,7 @@ int main(int argc, char* argv[]) {
                             // which kernel + copy are device time; convert = float -> u8 (+ rotation) on the host (0: done on the device);
                             // png = encode + write; total = process wall time up to here
             const ComputeApp::Timing& t = app.timing();
-            // (alloc = the storage buffer — inside run(), while the device renders, unless --serial-start; warmup = the warm-up call on
-            //  its helper thread, warmup_wait = what run() still waited for it: computeApp.h)
+            // (warmup = the warm-up call on its helper thread, warmup_wait = what run() still waited for it: computeApp.h)
             printf("{\"timing_ms\": {\"init\": %.3f, \"alloc\": %.3f, \"run\": %.3f, \"kernel\": %.3f, \"copy\": %.3f, \"convert\": %.3f, "
                    "\"png\": %.3f, \"total\": %.3f, \"warmup\": %.3f, \"warmup_wait\": %.3f}, "
                    "\"gpu_postprocess\": %s, \"gpus\": %d, \"overlap_start\": %s, \"reference_png\": %s}\n",

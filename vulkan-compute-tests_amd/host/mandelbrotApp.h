@@ -47,19 +47,14 @@ struct MandelbrotApp : public ComputeApp {
         return mc_context_warmup_mandelbrot(ctx, &q, gpuPostprocess ? 1 : 0);
     }
 
-    // gpuPostprocess: render + float->u8 on the device, 4 B/pixel cross PCIe instead of 16.  One GPU: launch, THEN allocate the
-    // storage buffer (while the device renders; mc_host_alloc: K4's 629 MB in 4 ms), then copy.
     virtual void runCommandBuffer() override {
-        if (multi) {
-            ensureStorage();
-            if (gpuPostprocess) check(mc_multi_mandelbrot_render_rgba8(multi, &params, rgba8.bytes()), "mc_multi_mandelbrot_render_rgba8");
-            else check(mc_multi_mandelbrot_render(multi, &params, buffer.data(), nullptr), "mc_multi_mandelbrot_render");
+        if (gpuPostprocess) {   // render + float->u8 on the device: 4 B/pixel cross PCIe instead of 16
+            if (multi) check(mc_multi_mandelbrot_render_rgba8(multi, &params, rgba8.bytes()), "mc_multi_mandelbrot_render_rgba8");
+            else check(mc_mandelbrot_render_rgba8(ctx, &params, rgba8.bytes()), "mc_mandelbrot_render_rgba8");
             return;
         }
-        check(mc_mandelbrot_render_begin(ctx, &params, gpuPostprocess ? 1 : 0), "mc_mandelbrot_render_begin");
-        ensureStorage();
-        if (gpuPostprocess) check(mc_render_end(ctx, rgba8.bytes(), rgba8.sizeBytes()), "mc_render_end");
-        else check(mc_render_end(ctx, buffer.data(), buffer.sizeBytes()), "mc_render_end");
+        if (multi) check(mc_multi_mandelbrot_render(multi, &params, buffer.data(), nullptr), "mc_multi_mandelbrot_render");
+        else check(mc_mandelbrot_render(ctx, &params, buffer.data(), nullptr), "mc_mandelbrot_render");
     }
 
     // mandelbrotApp.h:149-170: u8 = static_cast<uint8_t>(scale * c), alpha 255.  The cast is UB out of

@@ -86,23 +86,18 @@ struct PathtracerApp : public ComputeApp {
                                            (uint32_t)spheres.size() / 12, gpuPostprocess ? 1 : 0);
     }
 
-    // gpuPostprocess: render + float->u8 + 180-degree rotation on the device (pathtracerApp.h:202-243), 4 B/pixel copied.
-    // One GPU: launch, THEN allocate the storage buffer (while the device renders), then copy.
     virtual void runCommandBuffer() override {
         const uint32_t np = (uint32_t)planes.size() / 12, ns = (uint32_t)spheres.size() / 12;
-        if (multi) {
-            ensureStorage();
-            if (gpuPostprocess) check(mc_multi_pathtrace_render_rgba8(multi, &params, planes.data(), np, spheres.data(), ns, rgba8.bytes()),
-                                      "mc_multi_pathtrace_render_rgba8");
-            else check(mc_multi_pathtrace_render(multi, &params, planes.data(), np, spheres.data(), ns, buffer.data()),
-                       "mc_multi_pathtrace_render");
+        if (gpuPostprocess) {   // render + float->u8 + 180-degree rotation on the device (pathtracerApp.h:202-243), 4 B/pixel copied
+            if (multi) check(mc_multi_pathtrace_render_rgba8(multi, &params, planes.data(), np, spheres.data(), ns, rgba8.bytes()),
+                             "mc_multi_pathtrace_render_rgba8");
+            else check(mc_pathtrace_render_rgba8(ctx, &params, planes.data(), np, spheres.data(), ns, rgba8.bytes()),
+                       "mc_pathtrace_render_rgba8");
             return;
         }
-        check(mc_pathtrace_render_begin(ctx, &params, planes.data(), np, spheres.data(), ns, gpuPostprocess ? 1 : 0),
-              "mc_pathtrace_render_begin");
-        ensureStorage();
-        if (gpuPostprocess) check(mc_render_end(ctx, rgba8.bytes(), rgba8.sizeBytes()), "mc_render_end");
-        else check(mc_render_end(ctx, buffer.data(), buffer.sizeBytes()), "mc_render_end");
+        if (multi) check(mc_multi_pathtrace_render(multi, &params, planes.data(), np, spheres.data(), ns, buffer.data()),
+                         "mc_multi_pathtrace_render");
+        else check(mc_pathtrace_render(ctx, &params, planes.data(), np, spheres.data(), ns, buffer.data()), "mc_pathtrace_render");
     }
 
     // pathtracerApp.h:202-223

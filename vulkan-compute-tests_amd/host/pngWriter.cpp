@@ -7,6 +7,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sched.h>
+
+#include <cstdlib>
+#include <cstring>
 #include <thread>
 
 namespace pngwriter {
@@ -107,13 +111,44 @@ void compress_stripe(const uint8_t* rgba8, uint32_t w, int bpp, bool last, Strip
 
 }  // namespace
 
+// CPUs this process may actually run on: the smallest of the hardware count, the affinity mask and the cgroup CPU quota.  A one-GPU box
+// of the pool shows 256 CPUs and grants 16: 64 deflate workers or 256 conversion threads there are throttled by the quota, and K4's PNG
+// took 55 or 105 ms from one run to the next (profiles/r05_end_to_end.txt, r06_end_to_end.txt).
+int usableThreads() {
+    unsigned n = std::thread::hardware_concurrency();
+    if (!n) n = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+    auto quota = [](const char* path, const char* period_path) -> double {   // cgroup v2: "max 100000" | "1600000 100000"; v1: two files
+        FILE* f = std::fopen(path, "r");
+        if (!f) return 0.0;
+        char a[64] = {0};
+        double q = 0.0, per = 0.0;
+        if (period_path) {
+            if (std::fscanf(f, "%lf", &q) != 1) q = 0.0;
+            std::fclose(f);
+            f = std::fopen(period_path, "r");
+            if (!f) return 0.0;
+            if (std::fscanf(f, "%lf", &per) != 1) per = 0.0;
+        } else if (std::fscanf(f, "%63s %lf", a, &per) == 2) {
+            q = std::strcmp(a, "max") == 0 ? 0.0 : std::atof(a);
+        }
+        std::fclose(f);
+        return (q > 0.0 && per > 0.0) ? q / per : 0.0;
+    };
+    double q = quota("/sys/fs/cgroup/cpu.max", nullptr);
+    if (q <= 0.0) q = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+    if (q > 0.0) n = std::min<unsigned>(n, (unsigned)std::max(1.0, q + 0.5));
+    return (int)std::max(1u, n);
+}
+
 std::string encode(std::vector<uint8_t>& out, const uint8_t* rgba8, uint32_t w, uint32_t h, int threads) {
     if (!rgba8 || !w || !h) return "empty image";
     bool opaque = true;
     for (size_t i = 0; i < (size_t)w * h && opaque; i++) opaque = rgba8[4 * i + 3] == 255;
     const int bpp = opaque ? 3 : 4;
     // stripes of >= 64 KiB of raw data, at most 4 per worker thread
-    if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    if (threads <= 0) threads = usableThreads();
     threads = std::max(1, std::min(threads, 64));
     const size_t row_bytes = (size_t)w * bpp + 1;
     uint32_t min_rows = (uint32_t)std::max<size_t>(1, (64 * 1024 + row_bytes - 1) / row_bytes);
@@ -190,7 +225,7 @@ void convertStorage(const float* vec4, uint8_t* rgba8, uint32_t w, uint32_t h, f
                 o[0] = x86FloatToU8(scale * s.r); o[1] = x86FloatToU8(scale * s.g); o[2] = x86FloatToU8(scale * s.b); o[3] = 255u;
             }
     };
-    unsigned n = threads > 0 ? (unsigned)threads : std::thread::hardware_concurrency();
+    unsigned n = threads > 0 ? (unsigned)threads : (unsigned)usableThreads();
     n = std::max(1u, std::min(n, std::max(1u, h / 16u)));
     if (n == 1) { rows(0, h); return; }
     std::vector<std::thread> th;

@@ -19,6 +19,8 @@ inline uint8_t x86FloatToU8(float v) {
 }
 
 namespace pngwriter {
+// Worker threads `threads = 0` stands for: min(hardware, affinity mask, cgroup CPU quota) — not the 256 a 16-CPU container reports.
+int usableThreads();
 // getRenderedImage's loop (mandelbrotApp.h:159-166, pathtracerApp.h:212-219) over row stripes on `threads` host threads (0 = all):
 // out[4 i + c] = static_cast<uint8_t>(scale * vec4[i][c]) with the reference binary's x86-64 semantics (x86FloatToU8), alpha 255.
 // rotate180 = the path tracer's swap loop (pathtracerApp.h:236-243) applied while writing: every pixel changes places with its point
