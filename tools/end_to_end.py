@@ -2,9 +2,9 @@
 """Where the wall time of a whole app run goes ("end-to-end seconds incl. gather, D2H, convert, PNG,
 reported separately").  Runs the standalone apps — the reference's main.cpp flow: init, preRun, run, saveRenderedImage — as child
 processes with --timing-json for K2 (path trace 900 x 600 x 500), K1 and K4 (Mandelbrot 3200 x 2400 / 7680 x 5120 two-float), through
-both routes (bench.py: end_to_end), three times each (the best total is shown), next to a pinned device -> host copy of the same size.
-Round 6: every configuration twice — the apps' overlapped start (kernel family warmed up on a helper thread from init(), storage
-buffer allocated inside run() while the device renders) and `--serial-start`, the round-5 order, on the same build.
+both routes (bench.py: end_to_end), five times each (the best total is shown), next to a pinned device -> host copy of the same size.
+Round 6: every configuration twice — the apps' overlapped start (kernel family warmed up on a helper thread from init(); VERDICT r5
+item 2) and `--serial-start` (the first launch, with the code object's load, inside run()), on the same build.
     GPU box:  python tools/end_to_end.py > gpurun_out/r06_end_to_end.txt"""
 import os
 import sys
@@ -21,16 +21,16 @@ def main():
     sizes = sorted({bench.CONFIGS[c]["W"] * bench.CONFIGS[c]["H"] * b for c in cfgs for b in (16, 4)})
     probe = bench.pinned_copy_probe(sizes, torch)
     print("# pinned device -> host copy (torch, best of 5): " + ", ".join(f"{n / 1e6:.1f} MB {g:.1f} GB/s" for n, g in probe.items()))
-    print("# one cold app process per row, best total of 3; milliseconds.  init = HIP start-up + context; alloc = the pinned storage buffer; kernel / copy = device")
+    print("# one cold app process per row, best total of 5; milliseconds.  init = HIP start-up + context; alloc = the pinned storage buffer; kernel / copy = device")
     print("# time of the render (+ on-device conversion) and of the device -> host copy; convert = host float -> u8 (+ rotation), row stripes on all cores;")
     print("# png = encode + write (stripe-parallel zlib); total = process wall time from main() to the file being written")
-    print("# start: overlap = round 6 (warm-up on a helper thread from init(); the storage buffer allocated inside run(), after the launch), serial = --serial-start")
-    print("# (the round-5 order); alloc = the storage buffer (mc_host_alloc); warm = the warm-up call on its helper thread, w.wait = what run() still waited for it")
+    print("# start: overlap = round 6 (mc_context_warmup_* on a helper thread from init(), joined by run()), serial = --serial-start (first launch inside run());")
+    print("# alloc = the storage buffer (mc_host_alloc, in preRun()); warm = the warm-up call on its helper thread, w.wait = what run() still waited for it")
     print(f"# {'config':6s} {'route':12s} {'start':8s} {'init':>7s} {'alloc':>7s} {'warm':>6s} {'w.wait':>6s} {'run':>8s} {'kernel':>8s} {'copy':>7s} {'GB/s':>6s} "
           f"{'convert':>8s} {'png':>7s} {'total':>8s}   png bytes")
     for name in cfgs:
         for start, extra in (("overlap", ()), ("serial", ("--serial-start",))):
-            runs = [bench.end_to_end((name,), "fast", probe, extra) for _ in range(3)]
+            runs = [bench.end_to_end((name,), "fast", probe, extra) for _ in range(5)]
             for route in ("host_buffer", "rgba8"):
                 ok = [r[name][route] for r in runs if "error" not in r[name][route]]
                 if not ok:

@@ -35,7 +35,7 @@ profile3)   # K3's launch (3840 x 2560 x 4096 spp, 2 s) under the counters      
 fuzz)       # randomised campaigns on the final build                                                       -> profiles/r06_fuzz_*.log
   timeout -k 10 330 python tools/fuzz_parity.py --seconds 240 --seed 61 > $out/r06_fuzz_parity.log 2>&1; r1=$?
   timeout -k 10 330 python tools/fuzz_fast.py --seconds 240 --seed 62 --enclose --many > $out/r06_fuzz_fast.log 2>&1; r2=$?
-  tail -2 $out/r06_fuzz_parity.log $out/r06_fuzz_fast.log; [ $r1 -eq 0 ] && [ $r2 -eq 0 ] || exit 1 ;;
+  tail -n 2 $out/r06_fuzz_parity.log; tail -n 2 $out/r06_fuzz_fast.log; [ $r1 -eq 0 ] && [ $r2 -eq 0 ] || exit 1 ;;
 tests)
   timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $out/r06_gputest.log 2>&1; rc=$?; tail -5 $out/r06_gputest.log; [ $rc -eq 0 ] || exit $rc ;;
 *) echo "usage: $0 <section> ..."; exit 2 ;;
