@@ -31,6 +31,18 @@ def _deinterleave_numpy(gathered, H, n, block):
     return out
 
 
+def _assemble_rgba8_numpy(gathered, W, H, n, block, rotate180):
+    """numpy mirror of assemble_rgba8_kernel (csrc/postprocess.hip): output pixel (y, x) <- storage pixel (H-1-y, W-1-x), except an odd
+    width's middle column (pathtracerApp.h:236-243 swaps x < W/2 only), each storage row taken from its owner's tile."""
+    storage = _deinterleave_numpy(gathered, H, n, block)
+    if not rotate180:
+        return storage
+    out = storage[::-1, ::-1].copy()
+    if W % 2:
+        out[:, W // 2] = storage[:, W // 2]
+    return out
+
+
 def _worker(rank, world, port, W, H, q):
     sys.path.insert(0, ROOT)
     import __graft_entry__ as entry
@@ -59,6 +71,15 @@ def _worker(rank, world, port, W, H, q):
             g = S.gather_tiles(torch.from_numpy(pad), rank, world)
             if rank == 0:
                 results[name] = _deinterleave_numpy(g.numpy(), H, world, S.ROW_BLOCK)
+            if name == "pathtrace":
+                # round 6, the image route: every rank converts ITS tile (scale 1, no rotation) and sends 4 B/pixel; rank 0
+                # de-interleaves and applies the point reflection on bytes.  The oracle's float -> u8 stands in for the device conversion.
+                u8 = np.zeros((padded, W, 4), np.uint8)
+                if rows:
+                    u8[:len(rows)] = O.float_to_rgba8(pad[:len(rows)], 1.0).reshape(len(rows), W, 4)
+                g8 = S.gather_tiles(torch.from_numpy(u8), rank, world)
+                if rank == 0:
+                    results["pathtrace_rgba8"] = _assemble_rgba8_numpy(g8.numpy(), W, H, world, S.ROW_BLOCK, True)
             # the step loop bench.py runs (S.Exchange: receive buffers allocated once, two buffer sets used alternately): three
             # steps with different tile contents; what rank 0 re-assembles in step i must be step i's image
             ex = S.Exchange(rank, world, pad.shape, torch.from_numpy(pad).dtype, "cpu")
@@ -90,7 +111,7 @@ def _worker(rank, world, port, W, H, q):
 @pytest.mark.parametrize("world,H", [(2, 70), (2, 64), (4, 601), (4, 70), (8, 70), (8, 20)])
 def test_sharded_render_equals_single(O, B, world, H):
     """(8, 20): three row blocks for eight ranks — ranks 3..7 own no rows and contribute padding only."""
-    W = 24
+    W = 25 if (world, H) == (2, 70) else 24
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -104,6 +125,9 @@ def test_sharded_render_equals_single(O, B, world, H):
     assert np.array_equal(res["mandelbrot"], O.mandelbrot_iters(W, H, 100).astype(np.int32))
     full = O.pathtrace(W, H, 4, math_mode=O.MATH_MC)
     assert np.array_equal(res["pathtrace"].view(np.uint32), full.view(np.uint32))
+    # the RGBA8 exchange re-assembles to the image the reference's host post-process makes of the whole storage buffer (odd width 25
+    # in one case: the middle column the reference's swap loop never touches)
+    assert np.array_equal(res["pathtrace_rgba8"], O.rotate180(O.float_to_rgba8(full, 1.0).reshape(H, W, 4), W, H))
 
 
 def test_sharding_helpers(B):
