@@ -2,10 +2,10 @@
 # Runs the CPU test suite (-m "not gpu") with the oracle and the host helpers built under AddressSanitizer +
 # UndefinedBehaviorSanitizer (make -C oracle sanitize; make -C vulkan-compute-tests_amd host-sanitize).  CPU build only.
 # The Python interpreter is not instrumented, so libasan is preloaded; leak checking is off (CPython's own allocations).
-#   tools/run_cpu_sanitizers.sh [log]          default log: profiles/r05_cpu_sanitizers.log
+#   tools/run_cpu_sanitizers.sh [log]          default log: profiles/r06_cpu_sanitizers.log
 set -o pipefail
 cd "$(dirname "$0")/.."
-log=${1:-profiles/r05_cpu_sanitizers.log}
+log=${1:-profiles/r06_cpu_sanitizers.log}
 make -s -C oracle sanitize && make -s -C vulkan-compute-tests_amd host-sanitize || exit 1
 asan=$(gcc -print-file-name=libasan.so)
 {
