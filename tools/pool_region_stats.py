@@ -2,7 +2,9 @@
 csrc/pathtrace_pool.h how often a wave executes it per iteration and how many lanes are active when it does — K2 in fast math.
 The dynamic counterpart of tools/isa_blocks.py (static instructions per block); together they give the instruction budget of an
 iteration (profiles/r03_pool_region_stats.txt).  GPU box:
-  MC_LIB_PATH=vulkan-compute-tests_amd/lib/libmc_compute_stats.so python tools/pool_region_stats.py [spp]"""
+  MC_LIB_PATH=vulkan-compute-tests_amd/lib/libmc_compute_stats.so python tools/pool_region_stats.py [spp] [fast|careful|strict]
+Round 6: the counters of all three tiers' translation units are summed (mc_debug_pt_region_stats), so a careful or strict request —
+explicit, or what the host makes of a fast request on five or more spheres / an enclosed light — is counted too."""
 import ctypes as C
 import os
 import sys
@@ -19,6 +21,8 @@ L = B.lib()
 L.mc_debug_pt_region_stats.argtypes = [C.c_void_p, C.c_void_p]
 W, H = 900, 600
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+tier = sys.argv[2] if len(sys.argv) > 2 else "fast"
+mode = {"fast": B.PT_MATH_FAST, "careful": B.PT_MATH_FAST_CAREFUL, "strict": B.PT_MATH_STRICT}[tier]
 names = [(0, "iteration"), (1, "refill bookkeeping (some lane is free)"), (2, "batch of 64 camera rays + their intersection"),
          (22, "  root block, sphere 0 (camera rays)"), (23, "  root block, sphere 1"), (24, "  root block, sphere 2"),
          (3, "free lanes take a stash entry"), (4, "bounce: prologue"), (5, "  sphere normal"), (12, "  emission of the hit"),
@@ -29,10 +33,10 @@ names = [(0, "iteration"), (1, "refill bookkeeping (some lane is free)"), (2, "b
 with B.Context(0) as ctx:
     ex, ln = np.zeros(32, np.uint64), np.zeros(32, np.uint64)
     L.mc_debug_pt_region_stats(ex.ctypes.data, ln.ctypes.data)   # reset
-    ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST))
+    ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=mode))
     L.mc_debug_pt_region_stats(ex.ctypes.data, ln.ctypes.data)
 it = float(ex[0])
-print(f"K2 {W}x{H}x{spp}, fast sample-pool kernel: {int(ex[0])} wave-iterations ({it / (W * H / 4):.1f} per wave), "
+print(f"K2 {W}x{H}x{spp}, {tier} sample-pool kernel: {int(ex[0])} wave-iterations ({it / (W * H / 4):.1f} per wave), "
       f"{int(ln[4])} lane-bounces = {float(ln[4]) / (W * H * spp):.2f} per sample, {float(ln[4]) / it:.1f} of 64 lanes in a bounce")
 print(f"{'block':58s} {'runs per iteration':>18s} {'lanes when it runs':>18s} {'lane share':>10s}")
 for r, name in names:
