@@ -220,8 +220,8 @@ def end_to_end(cfg_names=("K2", "K4"), math="fast", probe=None, extra=()):
                    "the pinned storage buffer (mc_host_alloc), run = the blocking render call = kernel + copy (device time) + launch / sync, "
                    "convert = host float -> u8 (+ rotation; 0 when done on the device), png = encode + write, total = process wall time.  "
                    "Round 6: the apps warm the kernel family up on a helper thread from init() (warmup; warmup_wait = what run() still waited "
-                   "for it) and allocate the storage buffer inside run(), while the device renders: `kernel` no longer contains the code "
-                   "object's first use, `run` contains `alloc`")
+                   "for it): `kernel` no longer contains the code "
+                   "object's first use; and the host_buffer route converts inside the PNG writer's stripe workers: `convert` is 0, `png` contains it")
     return out
 
 

@@ -106,3 +106,30 @@ def test_reference_codec_on_these_pixels_gives_the_pinned_bytes(H, O):
     png = O.ref_png_encode(opaque(rgb), rgb.shape[1], rgb.shape[0])
     assert len(png) == 1057515
     assert hashlib.sha256(png).hexdigest() == open(os.path.join(GOLDEN, "readme_image_png.sha256")).read().split()[0]
+
+
+@pytest.mark.parametrize("shape", [(40, 60), (34, 51), (1, 1), (3, 7), (600, 900), (257, 263)])
+def test_storage_buffer_straight_to_png_is_the_two_step_file(H, O, shape):
+    """Round 6: the apps' storage-buffer route hands the fp32 vec4 buffer to the PNG writer, whose stripe workers convert the rows they
+    filter (getRenderedImage's x86 cast + the path tracer's point reflection, odd-width middle column included).  For every thread
+    count the file is BYTE FOR BYTE the one the two-step way produces (convertStorage, then encode), and its pixels are the oracle's."""
+    h, w = shape
+    rng = np.random.default_rng(h * 31 + w)
+    buf = (rng.random((h, w, 4), dtype=np.float32) * 300.0 - 20.0).astype(np.float32)     # out-of-range values: the wrap-around cast
+    buf[..., 3] = 0.0
+    H.mcu_png_encode_storage.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_ubyte)),
+                                         C.POINTER(C.c_size_t)]
+    H.mcu_convert_storage.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_int]
+    for scale, rotate in ((1.0, 1), (255.0 / 280.0, 0), (1.0, 0)):
+        exp = O.float_to_rgba8(buf, scale).reshape(h, w, 4)
+        if rotate:
+            exp = O.rotate180(exp, w, h)
+        for threads in (1, 3, 0):
+            out, n = C.POINTER(C.c_ubyte)(), C.c_size_t(0)
+            assert H.mcu_png_encode_storage(buf.ctypes.data_as(C.c_void_p), w, h, scale, rotate, threads, C.byref(out), C.byref(n)) == 0
+            fused = C.string_at(out, n.value)
+            H.mcu_free(out)
+            assert np.array_equal(decode(fused), exp), (scale, rotate, threads)
+            two = np.empty((h, w, 4), np.uint8)
+            H.mcu_convert_storage(buf.ctypes.data_as(C.c_void_p), two.ctypes.data_as(C.c_void_p), w, h, scale, rotate, threads)
+            assert fused == encode(H, two, threads), (scale, rotate, threads)

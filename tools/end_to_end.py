@@ -22,8 +22,8 @@ def main():
     probe = bench.pinned_copy_probe(sizes, torch)
     print("# pinned device -> host copy (torch, best of 5): " + ", ".join(f"{n / 1e6:.1f} MB {g:.1f} GB/s" for n, g in probe.items()))
     print("# one cold app process per row, best total of 5; milliseconds.  init = HIP start-up + context; alloc = the pinned storage buffer; kernel / copy = device")
-    print("# time of the render (+ on-device conversion) and of the device -> host copy; convert = host float -> u8 (+ rotation), row stripes on all cores;")
-    print("# png = encode + write (stripe-parallel zlib); total = process wall time from main() to the file being written")
+    print("# time of the render (+ on-device conversion) and of the device -> host copy; convert = host float -> u8 (+ rotation) as a pass of its own: 0 since")
+    print("# round 6 — the host_buffer route converts inside the PNG writer's stripe workers; png = (convert +) filter + deflate + write; total = main() to the file written")
     print("# start: overlap = round 6 (mc_context_warmup_* on a helper thread from init(), joined by run()), serial = --serial-start (first launch inside run());")
     print("# alloc = the storage buffer (mc_host_alloc, in preRun()); warm = the warm-up call on its helper thread, w.wait = what run() still waited for it")
     print(f"# {'config':6s} {'route':12s} {'start':8s} {'init':>7s} {'alloc':>7s} {'warm':>6s} {'w.wait':>6s} {'run':>8s} {'kernel':>8s} {'copy':>7s} {'GB/s':>6s} "

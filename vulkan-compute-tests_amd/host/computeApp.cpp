@@ -123,6 +123,10 @@ void ComputeApp::run() {
     if (!quiet) { printf("run() finished in %.3f ms\n", lastRunMs); fflush(stdout); }
 }
 
+std::string ComputeApp::writePngFromStorage(const char* filename, uint32_t w, uint32_t h, float scale, bool rotate180) const {
+    return pngwriter::encodeStorageFile(filename, buffer.data(), w, h, scale, rotate180, pngThreads);
+}
+
 std::string ComputeApp::writePng(const char* filename, const uint8_t* rgba8, uint32_t w, uint32_t h) const {
 #ifdef MC_HAVE_REFERENCE_PNG
     if (referencePng) {   // mandelbrotApp.h:181-183 / pathtracerApp.h:245-247: the reference's call and its error text

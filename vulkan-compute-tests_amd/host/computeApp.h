@@ -84,6 +84,11 @@ struct ComputeApp {
     // third-party codec (lodepng::encode, mandelbrotApp.h:181 / pathtracerApp.h:245): a reference tree that calls this library
     // (INTEGRATION.md route B) keeps that call and therefore its exact bytes; the standalone apps do not re-implement that codec.
     std::string writePng(const char* filename, const uint8_t* rgba8, uint32_t w, uint32_t h) const;
+    // The storage-buffer route's saveRenderedImage in one pass (round 6): the stripe workers of the PNG writer convert the rows they
+    // filter, so the RGBA8 intermediate image is never materialised; --reference-png needs that image (lodepng::encode takes it) and
+    // goes the two-step way.  Same file bytes as convertStorage + writePng.
+    bool fusedSave() const { return !gpuPostprocess && !referencePng; }
+    std::string writePngFromStorage(const char* filename, uint32_t w, uint32_t h, float scale, bool rotate180) const;
     double lastRunMilliseconds() const { return lastRunMs; }
     // Where the time of the last run() / saveRenderedImage() went (milliseconds; SURVEY §8d "end-to-end ... reported separately"):
     // device time of the kernels and of the device -> host copy (mc_context_last_timing; 0 for multi-GPU runs), the host

@@ -20,6 +20,16 @@ int mcu_png_encode_mt(const uint8_t* rgba8, uint32_t w, uint32_t h, int threads,
 int mcu_png_encode(const uint8_t* rgba8, uint32_t w, uint32_t h, uint8_t** out, size_t* out_len) {
     return mcu_png_encode_mt(rgba8, w, h, 0, out, out_len);
 }
+// The storage buffer straight to a PNG (conversion fused into the stripe workers): same bytes as mcu_convert_storage + mcu_png_encode_mt.
+int mcu_png_encode_storage(const float* vec4, uint32_t w, uint32_t h, float scale, int rotate180, int threads, uint8_t** out, size_t* out_len) {
+    std::vector<uint8_t> png;
+    if (!pngwriter::encodeStorage(png, vec4, w, h, scale, rotate180 != 0, threads).empty()) return 1;
+    *out = (uint8_t*)std::malloc(png.size());
+    if (!*out) return 2;
+    std::memcpy(*out, png.data(), png.size());
+    *out_len = png.size();
+    return 0;
+}
 void mcu_free(void* p) { std::free(p); }
 
 void mcu_float_to_u8(const float* in, uint8_t* out, size_t n) {

@@ -67,6 +67,14 @@ struct MandelbrotApp : public ComputeApp {
         std::vector<uint8_t> image;
         constexpr float scaleFactor = 255.0f;   // mandelbrotApp.h:174
         auto t0 = std::chrono::steady_clock::now();
+        if (fusedSave()) {   // getRenderedImage's cast inside the PNG writer's stripe workers: one pass over the storage buffer
+            printf("writing %s\n", png_filename);
+            std::string err = writePngFromStorage(png_filename, resx, resy, scaleFactor, false);
+            if (!err.empty()) printf("encoder error: %s", err.c_str());
+            times.convertMs = 0.0;
+            times.pngMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            return;
+        }
         if (!gpuPostprocess) getRenderedImage(image, resx, resy, scaleFactor);   // (else: converted on the device, same cast semantics)
         auto t1 = std::chrono::steady_clock::now();
         printf("writing %s\n", png_filename);

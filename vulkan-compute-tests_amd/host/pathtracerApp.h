@@ -110,6 +110,13 @@ struct PathtracerApp : public ComputeApp {
         constexpr float scaleFactor = 1.0f;   // pathtracerApp.h:227
         printf("writing %s\n", png_filename);
         auto t0 = std::chrono::steady_clock::now();
+        if (fusedSave()) {   // getRenderedImage + the rotation of :235-243 + the encoder in one pass over the storage buffer
+            std::string err = writePngFromStorage(png_filename, resx, resy, scaleFactor, true);
+            if (!err.empty()) printf("encoder error: %s", err.c_str());
+            times.convertMs = 0.0;
+            times.pngMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            return;
+        }
         if (!gpuPostprocess) {   // (else: converted and rotated on the device)
             // getRenderedImage, then: due to the pinhole camera the image is upside-down and mirrored — undo that (pathtracerApp.h:235-243:
             // every pixel of the left half swapped with its point reflection).  One pass here: each converted pixel is written to the

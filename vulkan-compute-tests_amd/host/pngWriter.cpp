@@ -85,14 +85,43 @@ template <int F> void filter_apply(const uint8_t* cur, const uint8_t* prev, size
 }
 }  // namespace
 
-void filter_rows(const uint8_t* rgba8, uint32_t w, uint32_t y0, uint32_t y1, int bpp, uint8_t* raw) {
+// Where a stripe's rows come from: an RGBA8 image (bpp 3 or 4 bytes kept per pixel), or — the apps' storage-buffer route since round 6 —
+// the fp32 vec4 storage buffer itself, converted row by row INSIDE the stripe worker (getRenderedImage's cast, mandelbrotApp.h:159-166 /
+// pathtracerApp.h:212-219, + the point reflection of :236-243): the 4 B/pixel intermediate image is never written or read back.
+struct RowSource {
+    const uint8_t* rgba8 = nullptr;   // either this ...
+    const float* vec4 = nullptr;      // ... or the storage buffer with
+    float scale = 1.0f;
+    bool rotate180 = false;
+    uint32_t w = 0, h = 0;
+    int bpp = 3;
+    void load(uint32_t y, uint8_t* dst) const {
+        if (rgba8) {
+            const uint8_t* src = rgba8 + (size_t)y * w * 4;
+            if (bpp == 4) std::memcpy(dst, src, (size_t)w * 4);
+            else for (uint32_t x = 0; x < w; x++) std::memcpy(dst + (size_t)x * 3, src + 4 * (size_t)x, 3);
+            return;
+        }
+        // output pixel (x, y) is storage pixel (w-1-x, h-1-y) — except an odd width's middle column, which the reference's swap loop
+        // (x < resx / 2) leaves where it was: convertStorage's rule, read from the output's side
+        const uint32_t mid = (w & 1u) ? w / 2 : w;   // (w: no such column)
+        const float* same = vec4 + (size_t)y * w * 4;
+        const float* refl = vec4 + (size_t)(h - 1 - y) * w * 4;
+        for (uint32_t x = 0; x < w; x++) {
+            const float* s = (rotate180 && x != mid) ? refl + 4 * (size_t)(w - 1 - x) : same + 4 * (size_t)x;
+            dst[3 * (size_t)x] = x86FloatToU8(scale * s[0]);
+            dst[3 * (size_t)x + 1] = x86FloatToU8(scale * s[1]);
+            dst[3 * (size_t)x + 2] = x86FloatToU8(scale * s[2]);
+        }
+    }
+};
+
+void filter_rows(const RowSource& src, uint32_t y0, uint32_t y1, uint8_t* raw) {
+    const uint32_t w = src.w;
+    const int bpp = src.bpp;
     const size_t stride = (size_t)w * bpp;
     std::vector<uint8_t> cur(stride), prev(stride, 0);
-    auto load = [&](uint32_t y, std::vector<uint8_t>& dst) {
-        const uint8_t* src = rgba8 + (size_t)y * w * 4;
-        if (bpp == 4) std::memcpy(dst.data(), src, stride);
-        else for (uint32_t x = 0; x < w; x++) std::memcpy(&dst[(size_t)x * 3], src + 4 * (size_t)x, 3);
-    };
+    auto load = [&](uint32_t y, std::vector<uint8_t>& dst) { src.load(y, dst.data()); };
     if (y0 > 0) load(y0 - 1, prev);
     for (uint32_t y = y0; y < y1; y++) {
         load(y, cur);
@@ -125,10 +154,10 @@ struct Stripe {
 
 // One stripe: filter + raw deflate.  Non-final stripes end on a byte boundary with Z_SYNC_FLUSH (an empty stored
 // block), so the concatenation of all stripes is ONE valid deflate stream (the pigz construction).
-void compress_stripe(const uint8_t* rgba8, uint32_t w, int bpp, bool last, Stripe& s) {
-    const size_t stride = (size_t)w * bpp;
+void compress_stripe(const RowSource& src, bool last, Stripe& s) {
+    const size_t stride = (size_t)src.w * src.bpp;
     std::vector<uint8_t> raw((stride + 1) * (size_t)(s.y1 - s.y0));
-    filter_rows(rgba8, w, s.y0, s.y1, bpp, raw.data());
+    filter_rows(src, s.y0, s.y1, raw.data());
     s.raw_len = raw.size();
     uLong ad = adler32(0L, Z_NULL, 0);
     for (size_t pos = 0; pos < raw.size();) {
@@ -185,11 +214,11 @@ int usableThreads() {
     return (int)std::max(1u, n);
 }
 
-std::string encode(std::vector<uint8_t>& out, const uint8_t* rgba8, uint32_t w, uint32_t h, int threads) {
-    if (!rgba8 || !w || !h) return "empty image";
-    bool opaque = true;
-    for (size_t i = 0; i < (size_t)w * h && opaque; i++) opaque = rgba8[4 * i + 3] == 255;
-    const int bpp = opaque ? 3 : 4;
+namespace {
+std::string encode_rows(std::vector<uint8_t>& out, const RowSource& src, int threads) {
+    const uint32_t w = src.w, h = src.h;
+    const int bpp = src.bpp;
+    const bool opaque = bpp == 3;
     // stripes of >= 64 KiB of raw data, at most 4 per worker thread
     if (threads <= 0) threads = usableThreads();
     threads = std::max(1, std::min(threads, 64));
@@ -207,7 +236,7 @@ std::string encode(std::vector<uint8_t>& out, const uint8_t* rgba8, uint32_t w, 
         for (;;) {
             uint32_t i = next.fetch_add(1);
             if (i >= n_stripes) break;
-            compress_stripe(rgba8, w, bpp, i + 1 == n_stripes, stripes[i]);
+            compress_stripe(src, i + 1 == n_stripes, stripes[i]);
         }
     };
     int nt = (int)std::min<uint32_t>((uint32_t)threads, n_stripes);
@@ -243,15 +272,43 @@ std::string encode(std::vector<uint8_t>& out, const uint8_t* rgba8, uint32_t w, 
     return "";
 }
 
-std::string encodeFile(const char* filename, const uint8_t* rgba8, uint32_t w, uint32_t h, int threads) {
-    std::vector<uint8_t> png;
-    std::string err = encode(png, rgba8, w, h, threads);
-    if (!err.empty()) return err;
+std::string write_file(const char* filename, const std::vector<uint8_t>& png) {
     FILE* f = std::fopen(filename, "wb");
     if (!f) return std::string("cannot open ") + filename;
     size_t n = std::fwrite(png.data(), 1, png.size(), f);
     std::fclose(f);
     return n == png.size() ? "" : "short write";
+}
+}  // namespace
+
+std::string encode(std::vector<uint8_t>& out, const uint8_t* rgba8, uint32_t w, uint32_t h, int threads) {
+    if (!rgba8 || !w || !h) return "empty image";
+    bool opaque = true;
+    for (size_t i = 0; i < (size_t)w * h && opaque; i++) opaque = rgba8[4 * i + 3] == 255;
+    RowSource src;
+    src.rgba8 = rgba8; src.w = w; src.h = h; src.bpp = opaque ? 3 : 4;
+    return encode_rows(out, src, threads);
+}
+
+// The storage buffer straight to a PNG: alpha is 255 by construction (mandelbrotApp.h:165, pathtracerApp.h:218), so the image is 8-bit RGB.
+// Same pixels as convertStorage + encode — the SAME FILE, in fact: the rows a stripe filters are the rows convertStorage would have written.
+std::string encodeStorage(std::vector<uint8_t>& out, const float* vec4, uint32_t w, uint32_t h, float scale, bool rotate180, int threads) {
+    if (!vec4 || !w || !h) return "empty image";
+    RowSource src;
+    src.vec4 = vec4; src.scale = scale; src.rotate180 = rotate180; src.w = w; src.h = h; src.bpp = 3;
+    return encode_rows(out, src, threads);
+}
+
+std::string encodeFile(const char* filename, const uint8_t* rgba8, uint32_t w, uint32_t h, int threads) {
+    std::vector<uint8_t> png;
+    std::string err = encode(png, rgba8, w, h, threads);
+    return err.empty() ? write_file(filename, png) : err;
+}
+
+std::string encodeStorageFile(const char* filename, const float* vec4, uint32_t w, uint32_t h, float scale, bool rotate180, int threads) {
+    std::vector<uint8_t> png;
+    std::string err = encodeStorage(png, vec4, w, h, scale, rotate180, threads);
+    return err.empty() ? write_file(filename, png) : err;
 }
 
 

@@ -34,6 +34,11 @@ void convertStorage(const float* vec4, uint8_t* rgba8, uint32_t w, uint32_t h, f
 // single-threaded deflate of the reference's lodepng path is the dominant end-to-end cost.
 std::string encode(std::vector<uint8_t>& out, const uint8_t* rgba8, uint32_t w, uint32_t h, int threads = 0);
 std::string encodeFile(const char* filename, const uint8_t* rgba8, uint32_t w, uint32_t h, int threads = 0);
+// The fp32 vec4 storage buffer straight to a PNG (round 6): every stripe worker converts the rows it filters — convertStorage's cast and
+// point reflection, row by row — so the RGBA8 intermediate (K4: 157 MB written and read back) does not exist.  The file is byte for byte
+// the one convertStorage + encode produce with the same thread count.
+std::string encodeStorage(std::vector<uint8_t>& out, const float* vec4, uint32_t w, uint32_t h, float scale, bool rotate180, int threads = 0);
+std::string encodeStorageFile(const char* filename, const float* vec4, uint32_t w, uint32_t h, float scale, bool rotate180, int threads = 0);
 }  // namespace pngwriter
 
 #endif  // PNGWRITER_H_
