@@ -324,6 +324,8 @@ def spawn_ranks(args):
         if not ln.startswith("{"):
             print(ln, file=sys.stderr)
     if p.returncode != 0:
+        for ln in lines:            # a line printed before the failure (exit 3 / 4 / 5: sync fallback, failed equality, multi block) is relayed
+            print(ln, flush=True)
         sys.exit(f"bench.py --gpus {args.gpus}: the launcher exited with {p.returncode}" if p.returncode > 0 else p.returncode)
     if len(lines) != 1:
         sys.exit(f"bench.py --gpus {args.gpus}: expected one JSON line from rank 0, got {len(lines)}")
@@ -546,6 +548,8 @@ def multi_block(job, args):
     Collective: every rank calls it.  Returns (block on rank 0 / None elsewhere, whether any rank's asynchronous exchange fell back)."""
     torch, dist = job.torch, job.dist
     rank, n = job.rank, job.n
+    if os.environ.get("MC_BENCH_INJECT_MULTI_FAILURE") == "1":      # tests: the failure path of main() (headline kept, exit 5)
+        raise RuntimeError("injected failure of the multi block")
     plan = {"K3": dict(steps=3, warmup=1, single_steps=1, single_warmup=0, exchange=args.exchange or "rgba8"),
             "K4": dict(steps=10, warmup=2, single_steps=5, single_warmup=1, exchange="f32")}
     block = {}
@@ -643,7 +647,9 @@ def main():
     if n > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=n, device_id=torch.device("cuda", device_index))
+            import datetime   # (180 s: the longest legitimate wait is rank 0's single-GPU K3 render, 2 s; a stuck collective ends the job)
+            dist.init_process_group("nccl", rank=rank, world_size=n, device_id=torch.device("cuda", device_index),
+                                    timeout=datetime.timedelta(seconds=int(os.environ.get("MC_BENCH_PG_TIMEOUT_S", "180"))))
         else:
             dist.init_process_group(backend, rank=rank, world_size=n)
     ctx = B.Context(device_index)
@@ -775,9 +781,19 @@ def main():
 
     # ---- BASELINE's 8-GPU configurations (K3, K4) from the plain command: N > 1, the default headline, nothing overridden ------------
     multi_failed = []
+    multi_error = None
     if n > 1 and args.multi:
         torch.cuda.empty_cache()
-        blk, multi_fell_back = multi_block(job, args)
+        # An exception in here (a rank that cannot allocate, a collective the backend refuses ...) must not cost the headline that was
+        # already measured: the line is printed with the error in `multi`, and the job exits 5.  (The other ranks of a stuck collective
+        # are ended by the launcher when this rank exits, or by the process group's timeout — 180 s, set at init.)
+        try:
+            blk, multi_fell_back = multi_block(job, args)
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            multi_error = f"rank {rank}: {e!r}"
+            print(f"[bench.py] the multi block failed on rank {rank}:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
+            blk, multi_fell_back = ({"error": multi_error, "failed_equality": []} if rank == 0 else None), False
         fell_back = fell_back or multi_fell_back
         if rank == 0:
             out["multi"] = blk
@@ -899,6 +915,11 @@ def main():
     # a multi block whose N-rank result differs from rank 0's single-GPU render.  Every rank takes the same exit (the flags were
     # all-reduced), after the process group is torn down.
     code = 0
+    if multi_error is not None:     # (no further collective: the ranks may no longer be in step)
+        if rank == 0:
+            print(f"bench.py: the multi block failed ({multi_error}); the headline above stands, exit 5", file=sys.stderr, flush=True)
+        ctx.close()
+        os._exit(5)                 # not sys.exit: destroying a process group with a collective in flight can block
     if n > 1:
         flags = torch.tensor([1.0 if fell_back else 0.0, float(len(multi_failed))], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(flags, op=dist.ReduceOp.MAX)

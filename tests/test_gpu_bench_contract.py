@@ -213,3 +213,18 @@ def test_app_default_math_is_reported_beside_the_headline():
     assert a["kernel_ms"] > 1.5 * a["headline_kernel_ms"] and 0.1 < a["frac"] < d["roofline"]["frac"]
     r = d["roofline"]
     assert "variant=shipped" in r["build_id"]
+
+
+def test_a_failing_multi_block_keeps_the_headline_and_fails_the_job():
+    """Round 6: whatever goes wrong inside the `multi` block on the first real multi-GPU run must not cost the headline that was already
+    measured, and must not pass for success: the line is printed with the error in `multi`, the job exits 5, and the plain command
+    relays both (injected failure; 2 ranks, gloo rehearsal)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], cwd=ROOT,
+                       env=dict(env, MC_BENCH_BACKEND="gloo", MC_BENCH_INJECT_MULTI_FAILURE="1"), capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "the multi block failed" in p.stderr, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    check_common(d, 2, 2, 1)
+    assert "injected failure" in d["multi"]["error"] and d["config"]["image"] == [900, 1200]
