@@ -199,7 +199,6 @@ static int run() {
 // transcendental ~8.2).  The path tracer's measured time is well under the sum of those prices, and a rewrite that removed
 // 4 % of its instructions made it slower — so: do classes overlap when they come from different waves, from one wave, and
 // what does an instruction cost whose EXEC mask is empty?
-// Build: hipcc --offload-arch=gfx950 -O2 -o tools/bin/valu_microbench3 tools/valu_microbench3.hip
 namespace mix {
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 constexpr int kIters = 2048;
@@ -316,7 +315,6 @@ static int run() {
 // v_rcp_f32 among adds at ~11.6 cycles (F F F T: 4.7 per instruction) against 8.2 in a stream of its own — is the difference a
 // price per SWITCH between the two pipes (then grouping the transcendentals of a block back to back pays), and does the
 // dependency of the next instruction on the transcendental's result matter?
-// Build: hipcc --offload-arch=gfx950 -O2 -o tools/bin/valu_microbench7 tools/valu_microbench7.hip
 namespace among {
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 constexpr int kIters = 2048;
@@ -415,7 +413,6 @@ static int run() {
 // only timed v_rcp_f32 / v_sqrt_f32; this one times every opcode the kernels use or could use — v_rcp, v_rsq, v_sqrt, v_sin, v_cos,
 // v_exp, v_log in f32 and the f16 forms — alone (16 per trip) and as 4 among 12 v_fmac_f32 (the in-kernel situation), at 6 waves per SIMD.
 // If an f16 form or exp / log were markedly cheaper, a seed + Newton step could replace an f32 transcendental.
-// Build: hipcc --offload-arch=gfx950 -O2 -o tools/bin/valu_microbench8 tools/valu_microbench8.hip
 namespace opcodes {
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 constexpr int kIters = 2048;

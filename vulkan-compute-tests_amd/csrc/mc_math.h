@@ -107,7 +107,7 @@ __device__ __forceinline__ float div_step(float a, float s, float y) {
 #define MC_PT_FAST_SHORT 0
 #endif
 #ifdef MC_EXPERIMENT_NO_TRANS
-// MEASUREMENT BUILD ONLY (make exp EXP_FLAGS=-DMC_EXPERIMENT_NO_TRANS; tools/pmc_libs.sh): the fast kernels' hardware transcendentals
+// MEASUREMENT BUILD ONLY (make exp EXP_FLAGS=-DMC_EXPERIMENT_NO_TRANS; profiled with round 4's tools/pmc_libs.sh, since removed: profiles/r04_no_trans_pmc.txt): the fast kernels' hardware transcendentals
 // replaced by ordinary-instruction approximations (bit-pattern seeds + two Newton steps; a parabola pair for sin / cos) good to ~1e-3 —
 // the paths stay statistically the same, the image is NOT the product's.  Answers one question: what does the SIMD pay per VALU
 // instruction when no transcendental is in the stream (profiles/r04_no_trans_pmc.txt)?

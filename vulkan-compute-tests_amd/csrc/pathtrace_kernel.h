@@ -212,7 +212,7 @@ static __device__ unsigned long long g_region_lanes[32];
 #ifndef MC_PT_FAST_PLANES_ONE_RCP   // fast math: one division for the three slab tests (intersect_slab)
 #define MC_PT_FAST_PLANES_ONE_RCP 1
 #endif
-// Fast-math forms that can be switched off one by one for A/B measurements (`make exp EXP_NAME=x EXP_FLAGS=-D<macro>=0`, tools/time_libs.py):
+// Fast-math forms that can be switched off one by one for A/B measurements (`make exp EXP_NAME=x EXP_FLAGS=-D<macro>=0`; tools/fork_census.py and tools/fast_tolerance_k2.py take such libraries):
 #ifndef MC_PT_FAST_TANGENT_ONE_RSQ      // light sample: sin_a / |tangent| as one A * rsq(A * B)
 #define MC_PT_FAST_TANGENT_ONE_RSQ 1
 #endif

@@ -95,8 +95,8 @@ void HostStorage::allocate(uint64_t bytes) {
 
 void ComputeApp::createBuffer(uint64_t bufferSizeBytes) {
     // In preRun(), where the reference allocates (vulkanComputeApp.cpp:489-533) — and BEFORE the render is launched: registering 629 MB
-    // with the runtime while a kernel runs (tried in round 6: allocate between mc_*_render_begin and mc_render_end) stalls the device —
-    // K4's kernel read 82 ms instead of 60 and the copy that followed 38 GB/s instead of 57 (profiles/r06_end_to_end.txt, first table).
+    // with the runtime while a kernel runs (tried in round 6: allocate between the launch and the copy of a two-phase render call, since withdrawn) stalls the device —
+    // K4's kernel read 82 ms instead of 60 and the copy that followed 38 GB/s instead of 57 (profiles/r06_end_to_end_rejected_b.txt).
     // mc_host_alloc makes the buffer in 4 ms; there is nothing left to hide.
     auto t0 = std::chrono::steady_clock::now();
     if (gpuPostprocess) rgba8.allocate(bufferSizeBytes / 4);   // 16 B/pixel of fp32 -> 4 B/pixel of RGBA8
