@@ -33,13 +33,14 @@
 // above keeps the reference's order.  It is deterministic: a wave's schedule depends on nothing outside the wave, and
 // the pixels a wave owns are the same for every tiling the host selects it for (pathtrace.hip).
 #pragma once
+#include <type_traits>
 #include "pathtrace_kernel.h"
 
 #ifndef MC_PT_POOL_WAVES
 #define MC_PT_POOL_WAVES 7   // waves per SIMD the register budget is set for (72 VGPRs; 6: 18.29 ms, 7: 18.11, 8: 18.68 at K2)
 #endif
 #ifndef MC_PT_POOL_STRICT_WAVES
-#define MC_PT_POOL_STRICT_WAVES 6   // strict kernel: 80 VGPRs (8 values spilled outside the bounce loop), 6 blocks of 26 KB per CU
+#define MC_PT_POOL_STRICT_WAVES 6   // strict kernel: 80 VGPRs (three values spilled, none reloaded inside an iteration), 6 blocks of 26 KB per CU
 #endif
 #ifndef MC_PT_POOL_KEEP_VALID   // the pixel's validity kept across the loop (a lane mask) instead of re-derived per batch
 #define MC_PT_POOL_KEEP_VALID 1
@@ -118,7 +119,10 @@ __global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_
     struct Lane { uint32_t lane, pix, sub, ty; bool valid; };
     auto my_lane = [&](bool with_row) {
         uint32_t tid = threadIdx.x;
-        if (!(MC_PT_POOL_LANE_REGS && !with_row)) asm volatile("" : "+v"(tid));   // (LANE_REGS: the refill's lane, sub stay in registers)
+        // (LANE_REGS: the refill's lane and sub stay in registers — the fast and careful kernels have the room.  The strict kernel at its
+        //  80-register budget has not: kept "in registers" they were spilled, and the lanes-below-me mask was reloaded from scratch in
+        //  the stash pick-up of nearly every iteration; there they are re-derived from the thread index, two instructions.)
+        if (!(MC_PT_POOL_LANE_REGS && Fast != 0 && !with_row)) asm volatile("" : "+v"(tid));
         Lane q;
         q.lane = tid & 63u; q.pix = q.lane / (uint32_t)S; q.sub = q.lane % (uint32_t)S;
         const uint32_t wave = tid >> 6;
@@ -138,6 +142,7 @@ __global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_
     // strict: my pixel's result ring [3][RRing] (x, y, z planes) behind the wave's stash
     float* const gres = lds_dyn + kPoolRecordFloats + (threadIdx.x >> 6) * pool_wave_lds_floats<Fast, NS>() + kPoolStashFloats +
                         ((threadIdx.x & 63u) / (uint32_t)S) * (3u * RRing);
+    // (re-deriving THIS address where it is used — path ends, commits — instead of keeping it was measured: + 1.1 ms at K2 strict)
     {
         const uint32_t tid = threadIdx.x, wave = tid >> 6, pix = (tid & 63u) / (uint32_t)S;
         gx = blockIdx.x * (2u * TW) + (wave & 1u) * TW + pix % TW;
@@ -162,7 +167,8 @@ __global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_
     }
     uint32_t cur = 0u;        // strict: index (within my pixel) of the sample this lane traces; its result slot is cur % RRing
     uint32_t committed = 0u;  // strict: samples of my pixel already added to acc (the same value in all S lanes)
-    const float fspp = (float)a.spp;
+    // (wave-uniform: held in a scalar register — as a vector value the strict kernel spilled it and reloaded it at every path end)
+    const float fspp = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)a.spp)));
     float emissive = 1.0f, t = 0.0f, occ[NS];
 #pragma unroll
     for (int i = 0; i < NS; i++) occ[i] = 0.0f;
@@ -195,10 +201,25 @@ __global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_
             if constexpr (!Fast) {
                 if (want) {   // (uniform) add the batches whose samples have all ended, in order; then: is the result ring free?
                     uint32_t oldest = alive ? cur : 0xffffffffu;                      // oldest sample a lane of my pixel still traces
+                    if constexpr (S == 16) {
+                        // The minimum over the pixel's 16 lanes = one DPP row: four rotations within the row (row_ror 8, 4, 2, 1), each
+                        // folded into its v_min_u32 — no LDS round trip and no address registers.  (The butterfly through ds_bpermute kept
+                        // four lane-address VGPRs live across the whole kernel; at the strict kernel's 80-register budget they were
+                        // spilled and RELOADED FROM SCRATCH here, inside the loop, each load waited for.)  Integer minimum: same value.
+                        auto rot_min = [](uint32_t v, auto ctrl) {
+                            const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, decltype(ctrl)::value, 0xf, 0xf, false);
+                            return o < v ? o : v;
+                        };
+                        oldest = rot_min(oldest, std::integral_constant<int, 0x128>{});   // row_ror:8
+                        oldest = rot_min(oldest, std::integral_constant<int, 0x124>{});   // row_ror:4
+                        oldest = rot_min(oldest, std::integral_constant<int, 0x122>{});   // row_ror:2
+                        oldest = rot_min(oldest, std::integral_constant<int, 0x121>{});   // row_ror:1
+                    } else {
 #pragma unroll
-                    for (uint32_t o = 1; o < (uint32_t)S; o <<= 1) {
-                        const uint32_t other = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((me.lane ^ o) << 2), (int)oldest);
-                        oldest = other < oldest ? other : oldest;
+                        for (uint32_t o = 1; o < (uint32_t)S; o <<= 1) {
+                            const uint32_t other = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((me.lane ^ o) << 2), (int)oldest);
+                            oldest = other < oldest ? other : oldest;
+                        }
                     }
                     const uint32_t fin = oldest < ghead ? oldest : ghead;             // samples [0, fin) are taken and ended
                     while (committed + (uint32_t)S <= fin) {
@@ -216,7 +237,11 @@ __global__ void __launch_bounds__(256, (pool_waves<Fast, NS>())) pathtrace_pool_
                 MC_REGION(2);    // a batch of camera rays
                 const Lane g = my_lane(MC_PT_POOL_KEEP_VALID ? false : true);
                 const uint32_t samp = a.sample_begin + batch * (uint32_t)S + g.sub;
-                const v3 crd = camera_ray<Fast>(a, gx, gy, samp);
+                // (strict: the pixel coordinates as fresh values — otherwise float(gy) of :359 is hoisted out of the loop, and at this
+                //  kernel's register budget "out of the loop" meant spilled and reloaded from scratch at the end of every iteration)
+                uint32_t cgx = gx, cgy = gy;
+                if constexpr (!Fast) asm volatile("" : "+v"(cgx), "+v"(cgy));
+                const v3 crd = camera_ray<Fast>(a, cgx, cgy, samp);
                 v3 oc0[NS];
                 float occ0[NS], ct;
 #pragma unroll
