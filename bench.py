@@ -256,7 +256,7 @@ def parse():
                     help="path tracer math mode: fast = gfx950 hardware transcendentals + contraction (toleranced parity, "
                          "tests/test_gpu_fullsize.py pins it at K2), careful = the fast mode's second tier asked for explicitly (no "
                          "contraction, division / sqrt / rsq rounded as the reference rounds them; the host selects it by itself from "
-                         "five spheres on), strict = IEEE + mc math (bit-identical to the oracle)")
+                         "four spheres on), strict = IEEE + mc math (bit-identical to the oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the end_to_end block (the standalone apps timed as child processes)")

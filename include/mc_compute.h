@@ -133,8 +133,8 @@ enum {
     MC_PT_MATH_STRICT = 0, /* IEEE div/sqrt + the explicit "mc math" sin/cos/pow: bit-identical to the oracle */
     MC_PT_MATH_FAST = 1,   /* toleranced parity (RMSE <= 0.5, 99.9-percentile per-pixel L2 <= 4 of 255 at 500 spp).  */
                            /* The library renders the request with whatever holds that bound on the scene given: the fast tier      */
-                           /* (gfx950 hardware rcp/rsq/sqrt/sin/cos/exp/log, a*b+c contracted) up to four spheres; the careful tier  */
-                           /* below from five spheres on; the strict kernels for a light all but enclosed by an opaque sphere.       */
+                           /* (gfx950 hardware rcp/rsq/sqrt/sin/cos/exp/log, a*b+c contracted) up to three spheres; the careful tier */
+                           /* below from four spheres on;  the strict kernels for a light all but enclosed by an opaque sphere.       */
                            /* mc_pathtrace_select_kernel reports which (mc_pathtrace_kernel_info.math_mode).                         */
     MC_PT_MATH_FAST_CAREFUL = 2 /* the fast mode's careful tier on request: the same kernels and shortcuts, division / sqrt / 1/sqrt */
                            /* rounded as the reference rounds them and no contraction — a sample differs from the reference's by far  */
@@ -228,16 +228,16 @@ int mc_context_warmup_mandelbrot(mc_context* ctx, const mc_mandelbrot_params* p,
  * mirror sphere.  Next-event estimation at point-blank range through rays grazing the sphere they start on (pathTracer.comp:325-327,
  * 420) makes such an image a collection of near-ties, which fast math decides differently from the reference arithmetic far more
  * often than its tolerance allows: an MC_PT_MATH_FAST request for such a scene is RENDERED WITH THE STRICT KERNELS
- * (bit-identical to the oracle), never silently outside the bound.  Bit 4 (MC_PT_SCENE_MANY_SPHERES) — any scene: five or more spheres.
+ * (bit-identical to the oracle), never silently outside the bound.  Bit 4 (MC_PT_SCENE_MANY_SPHERES) — any scene: four or more spheres.
  * The share of fast-math samples that take another path than the reference's grows with the number of (specular) spheres a path can
- * run through; the fast tier holds the bound with margin up to four, reads 3.2 of 4.0 at five and exceeds it from six on (4.4 .. 5.6;
- * profiles/r05_fork_census_careful.txt) — the switch is at FIVE, one sphere before the bound is crossed: an
+ * run through; on random boxes the fast tier holds the bound with three spheres (36 scenes, at most 3.3 of 4.0), misses it on 2 of 44 with
+ * four (5.5, 6.3), reads 3.2 with five and 4.4 .. 5.6 from six on (profiles/r05_fork_census_careful.txt, r06_fast_tier_{3,4}_spheres.txt): an
  * MC_PT_MATH_FAST request for such a scene is rendered by the careful tier (MC_PT_MATH_FAST_CAREFUL). */
 #define MC_PT_SCENE_SLAB 1u
 #define MC_PT_SCENE_LIGHTS_INSIDE 2u
 #define MC_PT_SCENE_SPHERES_DISJOINT 4u   /* slab scenes: the spheres are pairwise disjoint (the fast pool kernel then needs no square roots for shadow rays) */
 #define MC_PT_SCENE_LIGHT_ENCLOSED 8u     /* a light intersecting a diffuse sphere / all but enclosed by a mirror: fast math requests are rendered strict */
-#define MC_PT_SCENE_MANY_SPHERES 16u      /* any scene with five or more spheres: an MC_PT_MATH_FAST request is rendered by the careful tier            */
+#define MC_PT_SCENE_MANY_SPHERES 16u      /* any scene with four or more spheres: an MC_PT_MATH_FAST request is rendered by the careful tier            */
 int mc_pathtrace_scene_class(const float* planes, uint32_t n_planes, const float* spheres, uint32_t n_spheres,
                              uint32_t* out_class);
 

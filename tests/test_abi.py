@@ -290,17 +290,19 @@ def test_scene_classification_host_logic(B, O):
     assert B.pathtrace_scene_class(P, S[:2]) == SLAB | DISJOINT                       # (no light: nothing to skip)
     assert B.pathtrace_scene_class(P, S[1:]) == SLAB | INSIDE | DISJOINT
     five = np.concatenate([S, S[:2] + np.float32([0, 0, 2.2] + [0] * 9)])             # two more spheres in front, clear of the others
-    MANY = B.PT_SCENE_MANY_SPHERES     # five or more spheres: a fast request is rendered by the careful tier (round 5)
+    MANY = B.PT_SCENE_MANY_SPHERES     # four or more spheres: a fast request is rendered by the careful tier (round 5: five; round 6: four)
     assert B.pathtrace_scene_class(P, five) == SLAB | INSIDE | DISJOINT | MANY
-    assert B.pathtrace_scene_class(P, five[:4]) == SLAB | INSIDE | DISJOINT
+    assert B.pathtrace_scene_class(P, five[:4]) == SLAB | INSIDE | DISJOINT | MANY
+    assert B.pathtrace_scene_class(P, five[:3]) == SLAB | INSIDE | DISJOINT          # the reference scene: the fast tier
     nine = np.concatenate([S] * 3)
     assert B.pathtrace_scene_class(P, nine) & SLAB == 0                               # beyond 8: the generic kernel
     assert B.pathtrace_scene_class(P, nine) & MANY
     # ... and what mc_pathtrace_select_kernel reports for it: the careful tier runs; the fast tier only when a tool forces it
     fastq = B.pathtrace_params(300, 200, 500, math_mode=B.PT_MATH_FAST)
     assert B.pathtrace_select_kernel(fastq, P, five).math_mode == B.PT_MATH_FAST_CAREFUL
-    assert B.pathtrace_select_kernel(fastq, P, five[:4]).math_mode == B.PT_MATH_FAST
-    assert B.pathtrace_select_kernel(B.pathtrace_params(300, 200, 500, math_mode=B.PT_MATH_FAST_CAREFUL), P, five[:4]).math_mode == B.PT_MATH_FAST_CAREFUL
+    assert B.pathtrace_select_kernel(fastq, P, five[:4]).math_mode == B.PT_MATH_FAST_CAREFUL
+    assert B.pathtrace_select_kernel(fastq, P, five[:3]).math_mode == B.PT_MATH_FAST
+    assert B.pathtrace_select_kernel(B.pathtrace_params(300, 200, 500, math_mode=B.PT_MATH_FAST_CAREFUL), P, five[:3]).math_mode == B.PT_MATH_FAST_CAREFUL
     assert B.pathtrace_select_kernel(B.pathtrace_params(300, 200, 500, math_mode=B.PT_MATH_FAST, flags=B.PT_NO_FAST_GUARD), P, five).math_mode == B.PT_MATH_FAST
     assert B.pathtrace_select_kernel(B.pathtrace_params(300, 200, 500), P, five).math_mode == B.PT_MATH_STRICT
     with pytest.raises(B.McError):

@@ -135,11 +135,13 @@ static bool spheres_disjoint(const float* spheres, uint32_t n_spheres) {
 //     the bound for every position but the light's last sliver);
 //   * j of glass: never (next-event estimation does not pass glass, :420; the light is seen through refraction only), two lights: never.
 constexpr double kLightGapMargin = 1.5, kMirrorMargin = 0.25;
-// Spheres from which an MC_PT_MATH_FAST request is rendered by the careful tier.  Measured on the test suite's boxes (300 x 200 x 500,
-// bound 4; profiles/r05_fast_tiers.txt, r05_fast_tier_4_spheres.txt): the fast tier's 99.9-percentile reads 1.1 - 3.0 on sixteen random
-// boxes with three and four spheres, 3.2 with five, 4.4 - 4.5 with six and seven, 5.2 - 5.6 with eight (the generic kernels: 5.4 with
-// twelve, 8.0 with forty); the careful tier 0.65 with five, at most 1.14 with eight (generic: 0.84 / 1.81).
-constexpr uint32_t kCarefulSpheres = 5;
+// Spheres from which an MC_PT_MATH_FAST request is rendered by the careful tier.  Measured on the test suite's random boxes (300 x 200 x 500,
+// bound 4).  Round 5 set FIVE on a sample of sixteen boxes with three and four spheres (99.9-percentile 1.1 - 3.0; 3.2 with five, 4.4 - 5.6
+// with six to eight; the generic kernels 5.4 with twelve, 8.0 with forty).  Round 6 enlarged the sample (profiles/r06_fast_tier_{3,4}_spheres.txt):
+// of 32 more boxes with FOUR spheres two are outside — 5.5 (three specular spheres) and 6.3 (two lights) — and read 0.50 / 0.81 in the careful
+// tier; 32 more with THREE spheres stay inside (at most 3.3, median 1.5).  So the switch is at FOUR: the fast tier renders what it was
+// measured to hold — boxes with up to three spheres, the reference scene (K2: 2.49) among them.
+constexpr uint32_t kCarefulSpheres = 4;
 static bool light_nearly_enclosed_scan(const float* spheres, uint32_t n_spheres) {
     // the emissive spheres first (one pass; almost every scene has a handful), then each of them against the others
     std::vector<uint32_t> lights;
@@ -245,8 +247,8 @@ int pathtrace_plan(const mc_pathtrace_params* p, const float* planes, uint32_t n
     }
     // Fast math never runs where it cannot hold its tolerance: a scene with a light all but enclosed by an opaque sphere
     // (light_nearly_enclosed) is rendered strict; a scene with kCarefulSpheres or more spheres by the careful tier (pathtrace_careful.hip:
-    // the share of samples that fork grows with the sphere count; the fast tier's 99.9-percentile reads 3.2 of 4.0 at five spheres and exceeds
-    // the bound from six on — the switch sits one sphere before the crossing).
+    // the share of samples that fork grows with the sphere count; two of 44 random four-sphere boxes are outside the bound in the fast tier,
+    // none of 36 three-sphere ones — the switch is at four).
     plan.math_mode = p->math_mode;
     if (p->math_mode != MC_PT_MATH_STRICT && !(p->flags & MC_PT_NO_FAST_GUARD)) {
         if (light_nearly_enclosed(spheres, n_spheres)) plan.math_mode = MC_PT_MATH_STRICT;

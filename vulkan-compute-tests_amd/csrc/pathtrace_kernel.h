@@ -186,7 +186,7 @@ static __device__ unsigned long long g_region_lanes[32];
     } while (0)
 // The counters are per translation unit (fast / careful / strict tier): each defines a reader with this macro, and
 // mc_debug_pt_region_stats (pathtrace_fast.hip) sums the three — a request the host renders with the careful or the strict tier
-// (five or more spheres, an enclosed light, an explicit mode) is counted too.
+// (four or more spheres, an enclosed light, an explicit mode) is counted too.
 #define MC_PT_REGION_STATS_READER(name)                                                                              \
     int name(unsigned long long* exec32, unsigned long long* lanes32) {                                              \
         unsigned long long e[32], l[32], zero[32] = {0};                                                             \
