@@ -232,12 +232,19 @@ int mc_context_warmup_mandelbrot(mc_context* ctx, const mc_mandelbrot_params* p,
  * The share of fast-math samples that take another path than the reference's grows with the number of (specular) spheres a path can
  * run through; on random boxes the fast tier holds the bound with three spheres (36 scenes, at most 3.3 of 4.0), misses it on 2 of 44 with
  * four (5.5, 6.3), reads 3.2 with five and 4.4 .. 5.6 from six on (profiles/r05_fork_census_careful.txt, r06_fast_tier_{3,4}_spheres.txt): an
- * MC_PT_MATH_FAST request for such a scene is rendered by the careful tier (MC_PT_MATH_FAST_CAREFUL). */
+ * MC_PT_MATH_FAST request for such a scene is rendered by the careful tier (MC_PT_MATH_FAST_CAREFUL).  Bit 5 (MC_PT_SCENE_SPECULAR) — any
+ * scene with up to three spheres that has more specular surface than the reference scene (pathtracerApp.h:14-39: diffuse walls, one mirror
+ * and one glass sphere of r = 0.8): a mirror or glass wall, or mirror spheres (material 2), or glass spheres (material 3), whose squared radii
+ * sum to more than 0.65.  A forked sample that a specular chain carries to a light moves its pixel by the light's whole emission: of 148
+ * jittered three-sphere rooms thirteen are outside the bound in the fast tier (up to 8.0), eleven of them with a specular wall, two with mirror
+ * spheres beyond 0.65; the 56 rooms this bit leaves to the fast tier read at most 3.8, 26 of them drawn after the rule was set
+ * (profiles/r06_fast_tolerance_scenes*.txt).  The careful tier renders the others (at most 0.8). */
 #define MC_PT_SCENE_SLAB 1u
 #define MC_PT_SCENE_LIGHTS_INSIDE 2u
 #define MC_PT_SCENE_SPHERES_DISJOINT 4u   /* slab scenes: the spheres are pairwise disjoint (the fast pool kernel then needs no square roots for shadow rays) */
 #define MC_PT_SCENE_LIGHT_ENCLOSED 8u     /* a light intersecting a diffuse sphere / all but enclosed by a mirror: fast math requests are rendered strict */
 #define MC_PT_SCENE_MANY_SPHERES 16u      /* any scene with four or more spheres: an MC_PT_MATH_FAST request is rendered by the careful tier            */
+#define MC_PT_SCENE_SPECULAR 32u          /* up to three spheres, more specular surface than the reference scene's: likewise the careful tier          */
 int mc_pathtrace_scene_class(const float* planes, uint32_t n_planes, const float* spheres, uint32_t n_spheres,
                              uint32_t* out_class);
 
@@ -255,8 +262,8 @@ enum {
 typedef struct mc_pathtrace_kernel_info {
     uint32_t kernel;          /* MC_PT_KERNEL_*                                                                             */
     uint32_t lanes_per_pixel; /* sample-parallel width S: lanes of a wave that share a pixel (1, 4 or 16)                    */
-    uint32_t math_mode;       /* the mode that RUNS: for a fast request MC_PT_MATH_FAST, MC_PT_MATH_FAST_CAREFUL (MC_PT_SCENE_MANY_SPHERES) */
-                              /* or MC_PT_MATH_STRICT (MC_PT_SCENE_LIGHT_ENCLOSED)                                              */
+    uint32_t math_mode;       /* the mode that RUNS: for a fast request MC_PT_MATH_FAST, MC_PT_MATH_FAST_CAREFUL (MC_PT_SCENE_MANY_SPHERES,  */
+                              /* MC_PT_SCENE_SPECULAR) or MC_PT_MATH_STRICT (MC_PT_SCENE_LIGHT_ENCLOSED)                                    */
     uint32_t launches;        /* kernel launches per call (2: a ragged sample count in the round-synchronous kernels)        */
 } mc_pathtrace_kernel_info;
 int mc_pathtrace_select_kernel(const mc_pathtrace_params* p, const float* planes, uint32_t n_planes, const float* spheres,

@@ -32,7 +32,7 @@ enum {
                                     /* bit-identical either way                                                             */
     MC_PT_NO_FAST_GUARD = 1u << 6   /* run the fast TIER (tier 1) of MC_PT_MATH_FAST whatever the host's scene class says: neither     */
                                     /* the promotion to strict (MC_PT_SCENE_LIGHT_ENCLOSED) nor the promotion to the careful tier      */
-                                    /* (MC_PT_SCENE_MANY_SPHERES: four or more spheres) is applied — this is how tools force "tier 1"  */
+                                    /* (MC_PT_SCENE_MANY_SPHERES, MC_PT_SCENE_SPECULAR) is applied — this is how tools force "tier 1"     */
 };
 #define MC_PT_FORCE_S(s) ((uint32_t)(s) << 8) /* force the sample-parallel width: 1, 4 or 16 (0 = automatic) */
 

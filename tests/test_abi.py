@@ -294,6 +294,32 @@ def test_scene_classification_host_logic(B, O):
     assert B.pathtrace_scene_class(P, five) == SLAB | INSIDE | DISJOINT | MANY
     assert B.pathtrace_scene_class(P, five[:4]) == SLAB | INSIDE | DISJOINT | MANY
     assert B.pathtrace_scene_class(P, five[:3]) == SLAB | INSIDE | DISJOINT          # the reference scene: the fast tier
+    # up to three spheres: more specular surface than the reference scene's (one mirror and one glass sphere, r = 0.8: sum r^2 = 0.64 of each
+    # kind against 0.65; diffuse walls) -> careful tier
+    SPEC = B.PT_SCENE_SPECULAR
+    dark = ~S[:, 4:7].any(axis=1)
+    for kind in (2, 3):
+        (i,) = [i for i in range(3) if int(S[i, 11]) == kind]
+        assert abs(float(S[i, 3]) - 0.8) < 1e-6
+        bigger = S.copy(); bigger[i, 3] = 0.81
+        assert B.pathtrace_scene_class(P, bigger) & SPEC, kind
+        smaller = S.copy(); smaller[i, 3] = 0.5
+        assert not B.pathtrace_scene_class(P, smaller) & SPEC, kind
+        two = S.copy(); two[:, 11] = np.where(dark, kind, S[:, 11]); two[:, 3] = np.where(dark, 0.58, S[:, 3])
+        assert B.pathtrace_scene_class(P, two) & SPEC, kind                            # 2 x 0.58^2 = 0.67
+        two[:, 3] = np.where(dark, 0.56, S[:, 3])
+        assert not B.pathtrace_scene_class(P, two) & SPEC, kind                        # 2 x 0.56^2 = 0.63
+        wall = P.copy(); wall[4, 11] = kind
+        assert B.pathtrace_scene_class(wall, smaller) & SPEC, kind                     # any specular wall
+    assert B.pathtrace_scene_class(tilt, bigger) == SPEC                               # generic scenes, too
+    lit = S.copy(); lit[:, 11] = np.where(dark, S[:, 11], 2.0); lit[:, 3] = np.where(dark, 0.3, 0.81)
+    assert B.pathtrace_scene_class(P, lit) & SPEC                                      # a light that is a mirror reflects, too (pathTracer.comp:391, :432)
+    fastq3 = B.pathtrace_params(300, 200, 500, math_mode=B.PT_MATH_FAST)
+    assert B.pathtrace_select_kernel(fastq3, P, bigger).math_mode == B.PT_MATH_FAST_CAREFUL
+    assert B.pathtrace_select_kernel(fastq3, wall, S).math_mode == B.PT_MATH_FAST_CAREFUL
+    assert B.pathtrace_select_kernel(fastq3, P, S).math_mode == B.PT_MATH_FAST
+    assert B.pathtrace_select_kernel(B.pathtrace_params(300, 200, 500, math_mode=B.PT_MATH_FAST, flags=B.PT_NO_FAST_GUARD), wall, bigger).math_mode == B.PT_MATH_FAST
+    assert not B.pathtrace_scene_class(P, five) & SPEC                                 # four or more spheres: MANY has decided already
     nine = np.concatenate([S] * 3)
     assert B.pathtrace_scene_class(P, nine) & SLAB == 0                               # beyond 8: the generic kernel
     assert B.pathtrace_scene_class(P, nine) & MANY
@@ -351,7 +377,7 @@ def test_fast_math_guard_classification_and_kernel_query(B, O):
     assert with_gap(0.01, material=2.0) and with_gap(0.2 * light[3], material=2.0) and not with_gap(0.3 * light[3], material=2.0)
     assert not with_gap(0.01, material=3.0) and not with_gap(0.01, emissive_big=True)
     # any scene, not only slab ones (the generic kernels have the same fast mode)
-    assert B.pathtrace_scene_class(P[[2, 3, 0, 1, 4, 5]], S) == ENC
+    assert B.pathtrace_scene_class(P[[2, 3, 0, 1, 4, 5]], S) == ENC | B.PT_SCENE_SPECULAR     # (the fuzz case has a mirror wall)
     # the reference scene: pool kernel in both modes, the round-synchronous kernels for what the pool kernel does not take
     q = B.pathtrace_params(900, 600, 500, math_mode=B.PT_MATH_FAST)
     k = B.pathtrace_select_kernel(q)

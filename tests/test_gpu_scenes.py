@@ -248,7 +248,8 @@ def test_box_with_one_to_eight_spheres_runs_the_specialised_kernels(ctx, B, O, n
     rng = np.random.default_rng(40 + 10 * n_spheres + lights)
     planes, spheres = box_scene(O, n_spheres, rng, lights)
     cls = B.pathtrace_scene_class(planes, spheres)
-    assert cls == B.PT_SCENE_SLAB | B.PT_SCENE_LIGHTS_INSIDE | B.PT_SCENE_SPHERES_DISJOINT | (B.PT_SCENE_MANY_SPHERES if n_spheres >= 4 else 0), cls
+    specular = cls & B.PT_SCENE_SPECULAR         # up to three spheres, more specular surface than the reference scene's: careful tier, too
+    assert cls & ~B.PT_SCENE_SPECULAR == B.PT_SCENE_SLAB | B.PT_SCENE_LIGHTS_INSIDE | B.PT_SCENE_SPHERES_DISJOINT | (B.PT_SCENE_MANY_SPHERES if n_spheres >= 4 else 0), cls
     W, H, spp = 40, 24, 37
     ref = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC)
     p = B.pathtrace_params(W, H, spp)
@@ -269,7 +270,7 @@ def test_box_with_one_to_eight_spheres_runs_the_specialised_kernels(ctx, B, O, n
         q = B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, flags=flags)
         ki = B.pathtrace_select_kernel(q, planes, spheres)
         assert ki.kernel == (B.PT_KERNEL_BOX if flags else B.PT_KERNEL_POOL)
-        assert ki.math_mode == (B.PT_MATH_FAST_CAREFUL if n_spheres >= 4 else B.PT_MATH_FAST)
+        assert ki.math_mode == (B.PT_MATH_FAST_CAREFUL if n_spheres >= 4 or specular else B.PT_MATH_FAST)
         d = ctx.pathtrace(q, planes=planes, spheres=spheres)[..., :3].astype(np.float64) - libm
         rmse, p999 = float(np.sqrt((d ** 2).mean())), float(np.percentile(np.sqrt((d ** 2).sum(-1)), 99.9))
         print(f"{n_spheres} spheres / {lights} lights, flags {flags}: fast vs oracle(libm) rmse {rmse:.4f}  p99.9 L2 {p999:.3f}  mean {d.mean():+.5f}")
@@ -304,3 +305,34 @@ def test_four_sphere_boxes_that_broke_the_fast_tier_are_rendered_inside_the_boun
     assert p < 1.5, p                            # measured 0.50 / 0.81
     tier1, _, p1 = p999(B.PT_NO_FAST_GUARD)
     assert tier1 == B.PT_MATH_FAST and p1 > 4.0, (tier1, p1)   # the reason for the threshold, kept visible
+
+
+@pytest.mark.parametrize("index,why", [(0, "two mirror spheres and a mirror wall"), (30, "one mirror sphere, r = 0.88")])
+def test_three_sphere_rooms_that_broke_the_fast_tier_are_rendered_inside_the_bound(ctx, B, O, index, why):
+    """Round 6: 36 jittered three-sphere rooms (tools/fast_tolerance_scenes.py --seed 7, profiles/r06_fast_tolerance_scenes.txt) hold two
+    that the FAST tier renders outside the un-edited bound — these: p99.9 5.8 and 4.1.  What they share with every worst scene of the
+    censuses is mirror surface, so the host renders an MC_PT_MATH_FAST request for a scene with more of it than the reference scene has
+    (a mirror wall, or mirror spheres with sum r^2 > 0.65) with the careful tier: MC_PT_SCENE_SPECULAR.  As a caller makes the request both
+    are inside 0.5 / 4 with room; the fast tier forced by the measurement switch still shows why."""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from fast_tolerance_scenes import scene
+    rng = np.random.default_rng(7)
+    for _ in range(index + 1):
+        planes, spheres = scene(rng, O)
+    cls = B.pathtrace_scene_class(planes, spheres)
+    assert cls & B.PT_SCENE_SPECULAR and not cls & (B.PT_SCENE_MANY_SPHERES | B.PT_SCENE_LIGHT_ENCLOSED), (cls, why)
+    W, H, spp = 300, 200, 500
+    libm = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_LIBM)[..., :3].astype(np.float64)
+
+    def p999(flags):
+        q = B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, flags=flags)
+        d = ctx.pathtrace(q, planes=planes, spheres=spheres)[..., :3].astype(np.float64) - libm
+        return B.pathtrace_select_kernel(q, planes, spheres).math_mode, float(np.sqrt((d ** 2).mean())), float(np.percentile(np.sqrt((d ** 2).sum(-1)), 99.9))
+
+    tier, rmse, p = p999(0)
+    print(f"jittered room {index} ({why}): careful tier rmse {rmse:.4f} p99.9 {p:.3f}")
+    assert tier == B.PT_MATH_FAST_CAREFUL and rmse <= 0.5 and p <= 4.0, (tier, rmse, p)
+    tier1, _, p1 = p999(B.PT_NO_FAST_GUARD)
+    assert tier1 == B.PT_MATH_FAST and p1 > 4.0, (tier1, p1)   # the reason for the rule, kept visible

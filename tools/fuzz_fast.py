@@ -89,7 +89,7 @@ def main():
         ran = B.pathtrace_select_kernel(q, planes, spheres).math_mode      # the tier that rendered the request
         n["careful"] += int(ran == B.PT_MATH_FAST_CAREFUL)
         if (ran == B.PT_MATH_STRICT) != bool(cls & B.PT_SCENE_LIGHT_ENCLOSED) or \
-           (ran == B.PT_MATH_FAST_CAREFUL) != (bool(cls & B.PT_SCENE_MANY_SPHERES) and not cls & B.PT_SCENE_LIGHT_ENCLOSED):
+           (ran == B.PT_MATH_FAST_CAREFUL) != (bool(cls & (B.PT_SCENE_MANY_SPHERES | B.PT_SCENE_SPECULAR)) and not cls & B.PT_SCENE_LIGHT_ENCLOSED):
             bad.append(f"tier {ran} does not follow the scene class {cls} with {len(spheres)} spheres")
         if cls & B.PT_SCENE_LIGHT_ENCLOSED:   # classified outside the fast tolerance: the strict kernels must have rendered it
             n["guarded"] += 1

@@ -40,6 +40,16 @@ threshold)  # the fast tier's margin at FOUR spheres on a lar
             # spheres (one or two lights; half of them all-specular)                                           -> profiles/r06_fast_tier_4_spheres.txt
   timeout -k 10 1100 python tools/fork_census.py --modes tier1 --scenes "4:1:301:spec,4:1:302,4:1:303:spec,4:1:304,4:1:305:spec,4:1:306,4:1:307:spec,4:1:308,4:1:309:spec,4:1:310,4:1:311:spec,4:1:312,4:1:313:spec,4:1:314,4:1:315:spec,4:1:316,4:1:317:spec,4:1:318,4:1:319:spec,4:1:320,4:1:321:spec,4:1:322,4:1:323:spec,4:1:324,4:2:331:spec,4:2:332,4:2:333:spec,4:2:334,4:2:335:spec,4:2:336,4:2:337:spec,4:2:338" \
      vulkan-compute-tests_amd/lib/libmc_compute.so > $out/r06_fast_tier_4_spheres.txt 2>&1 || exit 1 ;;
+mirrors)    # the mirror rule: the 36 jittered three-sphere rooms it was set on (seed 7), as a caller requests them — the tier that ran, and the
+            # fast tier forced beside every promoted scene                                                  -> profiles/r06_fast_tolerance_scenes.txt
+  timeout -k 10 1100 python tools/fast_tolerance_scenes.py --scenes 36 --spp 500 --seed 7 > $out/r06_fast_tolerance_scenes.txt 2>&1 || exit 1
+  tail -n 3 $out/r06_fast_tolerance_scenes.txt ;;
+mirrors2)   # ... 48 more (seed 8: the specular-wall half of the rule was set here)                         -> profiles/r06_fast_tolerance_scenes_seed8.txt
+  timeout -k 10 1100 python tools/fast_tolerance_scenes.py --scenes 48 --spp 500 --seed 8 > $out/r06_fast_tolerance_scenes_seed8.txt 2>&1 || exit 1
+  tail -n 3 $out/r06_fast_tolerance_scenes_seed8.txt ;;
+mirrors3)   # ... and 64 rooms the rule has not seen (seed 9)                                               -> profiles/r06_fast_tolerance_scenes_validation.txt
+  timeout -k 10 1100 python tools/fast_tolerance_scenes.py --scenes 64 --spp 500 --seed 9 > $out/r06_fast_tolerance_scenes_validation.txt 2>&1 || exit 1
+  tail -n 3 $out/r06_fast_tolerance_scenes_validation.txt ;;
 tests)
   timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $out/r06_gputest.log 2>&1; rc=$?; tail -5 $out/r06_gputest.log; [ $rc -eq 0 ] || exit $rc ;;
 *) echo "usage: $0 <section> ..."; exit 2 ;;

@@ -224,6 +224,7 @@ def tile_rows(p):
 
 
 PT_SCENE_SLAB, PT_SCENE_LIGHTS_INSIDE, PT_SCENE_SPHERES_DISJOINT, PT_SCENE_LIGHT_ENCLOSED, PT_SCENE_MANY_SPHERES = 1, 2, 4, 8, 16
+PT_SCENE_SPECULAR = 32
 PT_KERNEL_GENERIC, PT_KERNEL_SLAB, PT_KERNEL_BOX, PT_KERNEL_POOL, PT_KERNEL_GENERIC_MEMORY = 0, 1, 3, 4, 5
 PT_KERNEL_NAMES = {0: "generic", 1: "slab", 3: "box", 4: "pool", 5: "generic_memory"}
 
