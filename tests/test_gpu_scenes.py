@@ -169,12 +169,13 @@ def test_fast_mode_on_a_scene_with_non_unit_plane_normals(ctx, B, O):
     planes[1, 0:4] *= 1.5          # right wall: normal (1.5, 0, 0), w scaled alike
     planes[2, 0:4] *= 0.75         # ceiling
     planes[4, 11] = 3.0            # the back wall refracts (tdir of :441 from a plane normal)
-    assert B.pathtrace_scene_class(planes, spheres) == 0
+    assert B.pathtrace_scene_class(planes, spheres) == B.PT_SCENE_SPECULAR   # generic; the glass wall: a fast request runs the careful tier
     W, H, spp = 96, 64, 64
     ref = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_LIBM)[..., :3].astype(np.float64)
     strict = ctx.pathtrace(B.pathtrace_params(W, H, spp), planes=planes, spheres=spheres)
     assert np.array_equal(bits(strict), bits(O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_MC)))
-    for flags in (0, B.pt_force_s(1), B.pt_force_s(16)):
+    # both tiers of the generic kernels: as requested (careful) and the fast tier through the measurement switch
+    for flags in (0, B.pt_force_s(1), B.pt_force_s(16), B.PT_NO_FAST_GUARD, B.PT_NO_FAST_GUARD | B.pt_force_s(1), B.PT_NO_FAST_GUARD | B.pt_force_s(16)):
         fast = ctx.pathtrace(B.pathtrace_params(W, H, spp, math_mode=B.PT_MATH_FAST, flags=flags), planes=planes, spheres=spheres)
         d = fast[..., :3].astype(np.float64) - ref
         rmse, p999 = np.sqrt((d ** 2).mean()), np.percentile(np.sqrt((d ** 2).sum(-1)), 99.9)
