@@ -337,3 +337,33 @@ def test_three_sphere_rooms_that_broke_the_fast_tier_are_rendered_inside_the_bou
     assert tier == B.PT_MATH_FAST_CAREFUL and rmse <= 0.5 and p <= 4.0, (tier, rmse, p)
     tier1, _, p1 = p999(B.PT_NO_FAST_GUARD)
     assert tier1 == B.PT_MATH_FAST and p1 > 4.0, (tier1, p1)   # the reason for the rule, kept visible
+
+
+def test_the_fast_tier_is_measured_not_guaranteed_the_known_room_at_its_limit(ctx, B, O):
+    """Round 6, said plainly: after the tier rule was set, 128 more jittered rooms (seeds 9 and 10) left 51 to the fast tier; 50 read at
+    most 3.76 of the bound 4 and ONE reads 4.21 — seed 10's room 42: diffuse walls, a glass sphere of r = 0.77 (no larger than the
+    reference scene's), a diffuse sphere, the light.  The rule was not bent around it (profiles/r06_fast_tolerance_scenes_validation2.txt;
+    DESIGN.md §4: 1 of 149 fast-tier scenes).  Kept here so that the limit stays visible: the host still selects the fast tier, which is
+    outside its bound by 5 % on this room; the careful tier, asked for, has an order of magnitude of room."""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from fast_tolerance_scenes import scene
+    rng = np.random.default_rng(10)
+    for _ in range(43):
+        planes, spheres = scene(rng, O)
+    assert B.pathtrace_scene_class(planes, spheres) & (B.PT_SCENE_SPECULAR | B.PT_SCENE_MANY_SPHERES | B.PT_SCENE_LIGHT_ENCLOSED) == 0
+    W, H, spp = 300, 200, 500
+    libm = O.pathtrace(W, H, spp, planes=planes, spheres=spheres, math_mode=O.MATH_LIBM)[..., :3].astype(np.float64)
+
+    def p999(mode):
+        q = B.pathtrace_params(W, H, spp, math_mode=mode)
+        d = ctx.pathtrace(q, planes=planes, spheres=spheres)[..., :3].astype(np.float64) - libm
+        return B.pathtrace_select_kernel(q, planes, spheres).math_mode, float(np.sqrt((d ** 2).mean())), float(np.percentile(np.sqrt((d ** 2).sum(-1)), 99.9))
+
+    tier, rmse, p = p999(B.PT_MATH_FAST)
+    print(f"seed 10 room 42, fast tier: rmse {rmse:.4f} p99.9 {p:.3f}")
+    assert tier == B.PT_MATH_FAST and rmse <= 0.5 and 4.0 < p < 4.5, (tier, rmse, p)     # the known limit: measured 0.244 / 4.207
+    tier, rmse, p = p999(B.PT_MATH_FAST_CAREFUL)
+    print(f"seed 10 room 42, careful tier: rmse {rmse:.4f} p99.9 {p:.3f}")
+    assert tier == B.PT_MATH_FAST_CAREFUL and rmse <= 0.5 and p <= 1.0, (tier, rmse, p)
