@@ -192,6 +192,15 @@ def end_to_end(cfg_names=("K2", "K4"), math="fast", probe=None, extra=()):
     import tempfile
     out = {}
     with tempfile.TemporaryDirectory(prefix="mc_e2e_") as tmp:
+        # The FIRST app process started on a box reads 100 - 300 ms more `init` than the second (binaries and the runtime's files not yet
+        # in the page cache: 186 and 357 ms against 70 on two boxes of round 6) — a property of the fresh box, not of a route: one
+        # discarded run first, its init reported beside the others
+        try:
+            p0 = subprocess.run(app_command(cfg_names[0], "rgba8", os.path.join(tmp, "discard.png"), math, extra), capture_output=True, text=True, timeout=600)
+            l0 = [ln for ln in p0.stdout.splitlines() if ln.startswith('{"timing_ms"')]
+            out["first_process_init"] = json.loads(l0[0])["timing_ms"]["init"] if l0 else None
+        except (OSError, subprocess.SubprocessError, ValueError, KeyError):
+            out["first_process_init"] = None
         for name in cfg_names:
             cfg = CONFIGS[name]
             entry = {"image": [cfg["W"], cfg["H"]]}
@@ -221,7 +230,8 @@ def end_to_end(cfg_names=("K2", "K4"), math="fast", probe=None, extra=()):
                    "convert = host float -> u8 (+ rotation; 0 when done on the device), png = encode + write, total = process wall time.  "
                    "Round 6: the apps warm the kernel family up on a helper thread from init() (warmup; warmup_wait = what run() still waited "
                    "for it): `kernel` no longer contains the code "
-                   "object's first use; and the host_buffer route converts inside the PNG writer's stripe workers: `convert` is 0, `png` contains it")
+                   "object's first use; and the host_buffer route converts inside the PNG writer's stripe workers: `convert` is 0, `png` contains it.  "
+                   "first_process_init = `init` of a discarded run started before the others (the first app process on a fresh box pays for cold files)")
     return out
 
 
