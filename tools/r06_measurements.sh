@@ -36,6 +36,10 @@ fuzz)       # randomised campaigns on the final build                           
   timeout -k 10 330 python tools/fuzz_parity.py --seconds 240 --seed 61 > $out/r06_fuzz_parity.log 2>&1; r1=$?
   timeout -k 10 330 python tools/fuzz_fast.py --seconds 240 --seed 62 --enclose --many > $out/r06_fuzz_fast.log 2>&1; r2=$?
   tail -n 2 $out/r06_fuzz_parity.log; tail -n 2 $out/r06_fuzz_fast.log; [ $r1 -eq 0 ] && [ $r2 -eq 0 ] || exit 1 ;;
+fuzz2)      # the same, 500 s each, other seeds, on the build with the specular tier rule                     -> profiles/r06_fuzz_*_c.log
+  timeout -k 10 560 python tools/fuzz_parity.py --seconds 500 --seed 65 > $out/r06_fuzz_parity_c.log 2>&1; r1=$?
+  timeout -k 10 560 python tools/fuzz_fast.py --seconds 500 --seed 66 --enclose --many > $out/r06_fuzz_fast_c.log 2>&1; r2=$?
+  tail -n 2 $out/r06_fuzz_parity_c.log; tail -n 2 $out/r06_fuzz_fast_c.log; [ $r1 -eq 0 ] && [ $r2 -eq 0 ] || exit 1 ;;
 threshold)  # the fast tier's margin at FOUR spheres on a larger sample — the fast tier forced on 32 more random boxes with four
             # spheres (one or two lights; half of them all-specular)                                           -> profiles/r06_fast_tier_4_spheres.txt
   timeout -k 10 1100 python tools/fork_census.py --modes tier1 --scenes "4:1:301:spec,4:1:302,4:1:303:spec,4:1:304,4:1:305:spec,4:1:306,4:1:307:spec,4:1:308,4:1:309:spec,4:1:310,4:1:311:spec,4:1:312,4:1:313:spec,4:1:314,4:1:315:spec,4:1:316,4:1:317:spec,4:1:318,4:1:319:spec,4:1:320,4:1:321:spec,4:1:322,4:1:323:spec,4:1:324,4:2:331:spec,4:2:332,4:2:333:spec,4:2:334,4:2:335:spec,4:2:336,4:2:337:spec,4:2:338" \
