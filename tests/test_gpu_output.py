@@ -276,6 +276,33 @@ def test_apps_overlapped_start_writes_the_same_file_as_the_serial_start(B, tmp_p
             assert files[0] == files[1], (app, args, route)
 
 
+def test_apps_leave_at_once_or_tear_down_on_request_same_file_same_exit_code(B, tmp_path):
+    """Once the picture is on disk and everything is printed the apps leave with _Exit: destroying the context, unregistering the storage
+    buffer and the HIP runtime's exit handlers cost 45 - 50 ms — a third of a K2 process — to return what the operating system reclaims
+    anyway (profiles/r06_init_spread_probe.txt).  --full-teardown runs them (what leak checkers and sanitizers want).  Same file, same
+    output, exit code 0 either way; the timing line carries CLOCK_MONOTONIC at main() and at the end, so that a parent can see what the
+    app's own `total` cannot contain — and the parent's clock shows the teardown."""
+    import json
+    import time
+    bindir = os.path.join(os.path.dirname(os.path.dirname(B.LIB_PATH)), "bin")
+    for app, args in (("pathtracer", ["6", "48", "--math", "fast"]), ("mandelbrot", ["--width", "320", "--height", "200", "--max-iter", "300"])):
+        files, after = [], []
+        for mode in ([], ["--full-teardown"]):
+            out = tmp_path / f"{app}{len(files)}.png"
+            t0 = time.monotonic()
+            r = subprocess.run([os.path.join(bindir, app)] + args + mode + ["--quiet", "--timing-json", "--out", str(out)], capture_output=True, text=True, cwd=tmp_path)
+            t1 = time.monotonic()
+            assert r.returncode == 0, r.stdout + r.stderr
+            j = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"timing_ms"')][0])
+            assert t0 * 1e3 <= j["main_at_ms"] <= j["end_at_ms"] <= t1 * 1e3
+            assert abs((j["end_at_ms"] - j["main_at_ms"]) - j["timing_ms"]["total"]) < 2.0
+            after.append(t1 * 1e3 - j["end_at_ms"])
+            files.append(open(out, "rb").read())
+        assert files[0] == files[1] and len(files[0]) > 100, app
+        print(f"{app}: after the file was written: {after[0]:.1f} ms (default), {after[1]:.1f} ms (--full-teardown)")
+        assert after[0] < 20.0, after          # measured 1 ms; 42 - 58 with the teardown
+
+
 def test_reference_png_mode_writes_the_reference_bytes(B, O, tmp_path):
     """VERDICT r5 item 3 / north_star "bit-identical PNG": route A with the reference's own codec.  `make REFERENCE=<checkout>`
     (what __graft_entry__.build() does where the checkout exists) compiles the reference's lodepng.cpp WHERE IT LIES into the apps

@@ -33,7 +33,7 @@ int main(int argc, char* argv[]) {
     // split options from positional arguments
     std::vector<const char*> pos;
     int gpus = 1;
-    bool quiet = false, gpuPost = false, timingJson = false, referencePng = false, overlapStart = true;
+    bool quiet = false, gpuPost = false, timingJson = false, referencePng = false, overlapStart = true, fullTeardown = false;
     int pngThreads = 0;
     const char* outFile = nullptr;
     uint32_t width = 2000, height = 2000, maxIter = 128, precision = MC_PRECISION_F32, mathMode = MC_PT_MATH_STRICT;
@@ -70,6 +70,7 @@ int main(int argc, char* argv[]) {
             mathMode = choice(argv[++i], {{"strict", MC_PT_MATH_STRICT}, {"fast", MC_PT_MATH_FAST}, {"careful", MC_PT_MATH_FAST_CAREFUL}});
         }
         else if (a == "--reference-png") referencePng = true;       // the reference's lodepng::encode (make REFERENCE=<checkout>)
+        else if (a == "--full-teardown") fullTeardown = true;        // run the destructors and the HIP runtime's exit handlers (see the end of main)
         else if (a == "--serial-start") overlapStart = false;        // measurements: the round-5 start-up order (no warm-up thread)
         else if (a == "--large-sphere-walls") largeSpheres = true;   // TEST_PRECISION_WITH_LARGE_SPHERE_WALLS (pathtracerApp.h:11)
         else if (a == "--sphere-precision") {                        // which #if branch of pathTracer.comp:132-256 is active
@@ -129,14 +130,27 @@ int main(int argc, char* argv[]) {
             // (warmup = the warm-up call on its helper thread, warmup_wait = what run() still waited for it: computeApp.h)
             printf("{\"timing_ms\": {\"init\": %.3f, \"alloc\": %.3f, \"run\": %.3f, \"kernel\": %.3f, \"copy\": %.3f, \"convert\": %.3f, "
                    "\"png\": %.3f, \"total\": %.3f, \"warmup\": %.3f, \"warmup_wait\": %.3f}, "
-                   "\"gpu_postprocess\": %s, \"gpus\": %d, \"overlap_start\": %s, \"reference_png\": %s}\n",
+                   "\"gpu_postprocess\": %s, \"gpus\": %d, \"overlap_start\": %s, \"reference_png\": %s, "
+                   "\"main_at_ms\": %.3f, \"end_at_ms\": %.3f}\n",
                    initMs, t.allocMs, t.runMs, t.kernelMs, t.copyMs, t.convertMs, t.pngMs, since(tStart), t.warmupMs,
-                   t.warmupWaitMs, gpuPost ? "true" : "false", gpus, overlapStart ? "true" : "false", referencePng ? "true" : "false");
+                   t.warmupWaitMs, gpuPost ? "true" : "false", gpus, overlapStart ? "true" : "false", referencePng ? "true" : "false",
+                   // CLOCK_MONOTONIC at main()'s first timed statement and now: a parent that reads the same clock around the process
+                   // gets what `total` cannot contain — loading + static initialisers before main(), teardown after it
+                   std::chrono::duration<double, std::milli>(tStart.time_since_epoch()).count(),
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count());
         }
     } catch (const std::runtime_error& e) {
         printf("%s\n", e.what());
         return EXIT_FAILURE;
     }
 
+    // The picture is on disk and everything is printed.  Destroying the context, unregistering the storage buffer and the HIP runtime's
+    // own exit handlers take another 45 - 50 ms (profiles/r06_init_spread_probe.txt: a third of a K2 process) to give back what the
+    // operating system reclaims at exit anyway: leave at once unless asked (--full-teardown: leak checkers, sanitizers, the tests).
+    if (!fullTeardown) {
+        fflush(stdout);
+        fflush(stderr);
+        std::_Exit(EXIT_SUCCESS);
+    }
     return EXIT_SUCCESS;
 }
