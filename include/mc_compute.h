@@ -200,8 +200,20 @@ int mc_convert_rgba8(mc_context* ctx, const float* rgba_f32, uint32_t width, uin
 /* Render + post-process fused on the device: the whole image is rendered, converted exactly as the reference's
  * saveRenderedImage would (Mandelbrot: scale 255, mandelbrotApp.h:159-174; path tracer: scale 1 and the
  * 180-degree rotation, pathtracerApp.h:202-243) and only the RGBA8 image (4 B/pixel instead of 16) is copied to
- * out_rgba8 (width*height*4 bytes, host).  Whole image only (row_begin = 0, row_end = height, no interleave). */
+ * out_rgba8 (width*height*4 bytes, host).  The path tracer: whole image only (row_begin = 0, row_end = height, no interleave).
+ * The Mandelbrot set, which is not rotated: also a contiguous band of rows [row_begin, row_end) (no interleave) — out_rgba8 then receives
+ * (row_end-row_begin)*width*4 bytes, the band's rows of the whole image's RGBA8 (the app renders band by band while its PNG workers run). */
 int mc_mandelbrot_render_rgba8(mc_context* ctx, const mc_mandelbrot_params* p, uint8_t* out_rgba8);
+/* The same image (rows [row_begin, row_end), no interleave) rendered in bands of band_rows rows, PIPELINED: band k + 1 is launched on a second
+ * stream before band k has finished — it fills the device while band k's last tiles drain and while band k's rows travel to the host — and
+ * on_rows(rows_done, user) is called on the calling thread as each band has ARRIVED, in order (rows [row_begin, rows_done) of the output are
+ * final): the caller's own work on the image — the app's PNG workers — runs beside the rest of the render.  Exactly one of out_rgba_f32
+ * (the storage buffer, 16 B/pixel) and out_rgba8 (converted on the device, 4 B/pixel) is non-NULL; on_rows may be NULL.  Blocking; the
+ * bytes are those of mc_mandelbrot_render / mc_mandelbrot_render_rgba8.  mc_context_last_timing then reports kernel = first launch to the end
+ * of the last kernel, copy = what of the copies was not hidden behind a kernel.  mc_context_warmup_mandelbrot(ctx, p, rgba8 | 2) prepares it. */
+typedef void (*mc_rows_ready_fn)(uint32_t rows_done, void* user);
+int mc_mandelbrot_render_banded(mc_context* ctx, const mc_mandelbrot_params* p, float* out_rgba_f32, uint8_t* out_rgba8, uint32_t band_rows,
+                                mc_rows_ready_fn on_rows, void* user);
 int mc_pathtrace_render_rgba8(mc_context* ctx, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
                               const float* spheres, uint32_t n_spheres, uint8_t* out_rgba8);
 
@@ -215,7 +227,8 @@ int mc_pathtrace_render_rgba8(mc_context* ctx, const mc_pathtrace_params* p, con
  * it from a helper thread while it does other start-up work (allocating its storage buffer, opening its output), and joins that
  * thread before its next call on the context (a context is not thread-safe).  (Round 6 also tried to move the storage buffer's
  * allocation BEHIND the launch with a two-phase render call: registering host memory while a kernel runs stalls the device — K4's
- * kernel 82 ms instead of 60 — so the buffer is made first, in 4 ms, and the blocking calls stayed as they were.) */
+ * kernel 82 ms instead of 60 — so the buffer is made first, in 4 ms, and the blocking calls stayed as they were.)
+ * mc_context_warmup_mandelbrot's `rgba8`: bit 0 as above, bit 1 = mc_mandelbrot_render_banded will follow (its second stream is made now). */
 int mc_context_warmup_pathtrace(mc_context* ctx, const mc_pathtrace_params* p, const float* planes, uint32_t n_planes,
                                 const float* spheres, uint32_t n_spheres, int rgba8);
 int mc_context_warmup_mandelbrot(mc_context* ctx, const mc_mandelbrot_params* p, int rgba8);

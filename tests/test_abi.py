@@ -425,5 +425,7 @@ def test_round6_entry_points_validate_without_gpu(B):
     assert L.mc_context_warmup_pathtrace(None, None, None, 0, None, 0, 0) == 1
     assert L.mc_context_warmup_mandelbrot(None, None, 0) == 1
     assert L.mc_assemble_rgba8_device_async(None, None, 1, 1, 1, 8, 1, 0, None, None) == 1
+    L.mc_mandelbrot_render_banded.argtypes = [vp, vp, vp, vp, C.c_uint32, vp, vp]
+    assert L.mc_mandelbrot_render_banded(None, None, None, None, 64, None, None) == 1
     out = subprocess.check_output(["readelf", "-d", B.LIB_PATH], text=True)
     assert "librccl" not in out and "libamdhip64" in out

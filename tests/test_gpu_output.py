@@ -26,6 +26,15 @@ def test_render_rgba8_equals_host_postprocess(ctx, B, O):
     assert L.mc_mandelbrot_render_rgba8(ctx._h, C.byref(p), out.ctypes.data_as(C.c_void_p)) == 0
     _, lut_u8 = O.mandel_lut(M)
     assert np.array_equal(out, lut_u8[O.mandelbrot_iters(W, H, M)])
+    # ... and in contiguous row bands (round 6, the app's streamed save): each band lands where the whole image has it; an interleaved
+    # tile is refused
+    banded = np.zeros((H, W, 4), np.uint8)
+    for r0, r1 in ((0, 64), (64, 65), (65, 200), (200, H)):
+        pb = B.mandelbrot_params(W, H, max_iter=M, row_begin=r0, row_end=r1)
+        assert L.mc_mandelbrot_render_rgba8(ctx._h, C.byref(pb), banded[r0:r1].ctypes.data_as(C.c_void_p)) == 0
+    assert np.array_equal(banded, out)
+    pb = B.mandelbrot_params(W, H, max_iter=M, row_begin=0, row_end=H, row_block=8, row_stride=16)
+    assert L.mc_mandelbrot_render_rgba8(ctx._h, C.byref(pb), banded.ctypes.data_as(C.c_void_p)) == 1
     # path tracer (odd width: the reference's middle-column quirk included)
     for W, H in ((48, 32), (51, 30)):
         q = B.pathtrace_params(W, H, 5)
@@ -39,6 +48,35 @@ def test_render_rgba8_equals_host_postprocess(ctx, B, O):
     q = B.pathtrace_params(48, 32, 5, sample_end=3)
     assert L.mc_pathtrace_render_rgba8(ctx._h, C.byref(q), planes.ctypes.data_as(C.c_void_p), 6,
                                        spheres.ctypes.data_as(C.c_void_p), 3, out.ctypes.data_as(C.c_void_p)) == 1
+
+
+@pytest.mark.parametrize("precision", ["f32", "ds"])
+def test_banded_render_is_the_blocking_render_band_by_band(ctx, B, O, precision):
+    """mc_mandelbrot_render_banded (round 6): the image in pipelined row bands — band k + 1 launched on a second stream before band k has
+    finished — with a callback as each band has arrived on the host.  Same bytes as mc_mandelbrot_render / mc_mandelbrot_render_rgba8
+    (the kernels are tiling-invariant), the callback hears the band ends in order, a row range of the image works, and
+    mc_context_last_timing answers afterwards."""
+    W, H, M = 333, 211, 200
+    prec = B.PRECISION_DS if precision == "ds" else B.PRECISION_F32
+    kw = dict(max_iter=M, precision=prec, centre=(-0.7436438870371587, 0.1318259042053119), scale=(3e-4, 2e-4)) if precision == "ds" else dict(max_iter=M)
+    whole, _ = ctx.mandelbrot(B.mandelbrot_params(W, H, **kw), want_iters=False)
+    whole8 = ctx.convert_rgba8(whole, 255.0)
+    for band_rows in (1000, 64, 37, 1):
+        for rgba8 in (False, True):
+            img, heard = ctx.mandelbrot_banded(B.mandelbrot_params(W, H, **kw), band_rows, rgba8=rgba8)
+            want = whole8 if rgba8 else whole
+            assert img.dtype == want.dtype and np.array_equal(img.view(np.uint8), want.view(np.uint8)), (band_rows, rgba8)
+            bands = (H + band_rows - 1) // band_rows
+            assert heard == [H * (b + 1) // bands for b in range(bands)], (band_rows, heard)
+            k_ms, c_ms = ctx.last_timing()
+            assert k_ms > 0 and c_ms >= 0
+    img, heard = ctx.mandelbrot_banded(B.mandelbrot_params(W, H, row_begin=40, row_end=171, **kw), 50)
+    assert np.array_equal(img.view(np.uint32), whole[40:171].view(np.uint32)) and heard == [40 + 131 * (b + 1) // 3 for b in range(3)]
+    with pytest.raises(B.McError):
+        ctx.mandelbrot_banded(B.mandelbrot_params(W, H, row_block=8, row_stride=16, **kw), 64)
+    # the blocking calls' timing is their own again afterwards
+    ctx.mandelbrot(B.mandelbrot_params(W, H, **kw), want_iters=False)
+    assert ctx.last_timing()[0] > 0
 
 
 def test_multi_rgba8_one_device(ctx, B, O, monkeypatch):
@@ -274,6 +312,37 @@ def test_apps_overlapped_start_writes_the_same_file_as_the_serial_start(B, tmp_p
                     assert t["timing_ms"]["warmup"] > 0 and t["timing_ms"]["alloc"] > 0
                 files.append(open(out, "rb").read())
             assert files[0] == files[1], (app, args, route)
+
+
+def test_mandelbrot_app_streams_its_save_and_writes_the_same_file(B, O, tmp_path):
+    """bin/mandelbrot renders its image in row bands and its PNG workers filter and deflate band k while the device renders band k + 1
+    (ComputeApp::setStreamedSave, mc_mandelbrot_render_banded, pngwriter::Progressive) — by default where it pays (W x H x M >= 1e11: K4,
+    not K1), always with --streamed-save; --no-streamed-save renders everything first, then encodes.  Same file bytes,
+    both routes, fp32 and two-float, 1 .. 3 bands and a height that is no multiple of anything; the timing line says how many bands ran;
+    the pixels are the oracle's."""
+    import json
+    app = os.path.join(os.path.dirname(os.path.dirname(B.LIB_PATH)), "bin", "mandelbrot")
+    for size, extra in ((("700", "1283"), ["--max-iter", "300"]), (("640", "1900"), ["--max-iter", "200", "--precision", "ds"]), (("320", "200"), [])):
+        args = ["--width", size[0], "--height", size[1]] + extra
+        for route in ([], ["--gpu-postprocess"]):
+            files = []
+            for mode in (["--streamed-save"], ["--no-streamed-save"], []):   # (default: only where it pays, W x H x M >= 1e11 — not here)
+                out = tmp_path / f"m{len(files)}.png"
+                r = subprocess.run([app] + args + route + mode + ["--quiet", "--timing-json", "--out", str(out)], capture_output=True, text=True, cwd=tmp_path)
+                assert r.returncode == 0, r.stdout + r.stderr
+                t = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"timing_ms"')][0])["timing_ms"]
+                assert t["streamed_bands"] == ((int(size[1]) + 639) // 640 if mode == ["--streamed-save"] else 0), t
+                assert t["kernel"] > 0 and t["copy"] >= 0
+                files.append(open(out, "rb").read())
+            assert files[0] == files[1] == files[2], (args, route)
+    # a request above the line streams by itself: 2000 x 1300 at M = 50 000 (1.3e11; the reference view: mostly early escapes, cheap)
+    r = subprocess.run([app, "--width", "2000", "--height", "1300", "--max-iter", "50000", "--quiet", "--timing-json", "--out", str(tmp_path / "big.png")],
+                       capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0 and json.loads([l for l in r.stdout.splitlines() if l.startswith('{"timing_ms"')][0])["timing_ms"]["streamed_bands"] == 3
+    # the pixels of the last image (320 x 200, the reference's M = 128): the oracle's
+    Image = pytest.importorskip("PIL.Image")
+    _, lut_u8 = O.mandel_lut(128)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "m0.png").convert("RGBA")), lut_u8[O.mandelbrot_iters(320, 200, 128)])
 
 
 def test_apps_leave_at_once_or_tear_down_on_request_same_file_same_exit_code(B, tmp_path):

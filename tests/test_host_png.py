@@ -133,3 +133,31 @@ def test_storage_buffer_straight_to_png_is_the_two_step_file(H, O, shape):
             two = np.empty((h, w, 4), np.uint8)
             H.mcu_convert_storage(buf.ctypes.data_as(C.c_void_p), two.ctypes.data_as(C.c_void_p), w, h, scale, rotate, threads)
             assert fused == encode(H, two, threads), (scale, rotate, threads)
+
+
+@pytest.mark.parametrize("w,h", [(97, 61), (640, 480), (1500, 1100)])
+def test_progressive_encoder_gives_the_one_shot_file(H, O, w, h):
+    """Round 6: the Mandelbrot app renders its image in row bands and feeds pngwriter::Progressive — the stripe workers filter and deflate
+    band k while the device renders band k + 1.  Same stripes, same bytes as the one-shot encoders, however the rows arrived: here the
+    buffer the workers read holds garbage until a band is copied in and declared ready (a worker that ran ahead would encode it)."""
+    rng = np.random.default_rng(h * 17 + w)
+    buf = (rng.random((h, w, 4), dtype=np.float32) * 300.0 - 20.0).astype(np.float32)
+    buf[..., 3] = 0.0
+    H.mcu_png_encode_storage.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_ubyte)),
+                                         C.POINTER(C.c_size_t)]
+    H.mcu_png_encode_progressive.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_int, C.c_int,
+                                             C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_size_t)]
+    rgba = O.float_to_rgba8(buf, 1.0).reshape(h, w, 4).copy()
+    for threads in (1, 3, 0):
+        out, n = C.POINTER(C.c_ubyte)(), C.c_size_t(0)
+        assert H.mcu_png_encode_storage(buf.ctypes.data_as(C.c_void_p), w, h, 1.0, 0, threads, C.byref(out), C.byref(n)) == 0
+        one_shot = C.string_at(out, n.value)
+        H.mcu_free(out)
+        assert one_shot == encode(H, rgba, threads)
+        for bands in (1, 2, 7, h):
+            for route, image in ((0, buf), (1, rgba)):
+                out, n = C.POINTER(C.c_ubyte)(), C.c_size_t(0)
+                assert H.mcu_png_encode_progressive(image.ctypes.data_as(C.c_void_p), w, h, 1.0, route, threads, bands, C.byref(out), C.byref(n)) == 0
+                got = C.string_at(out, n.value)
+                H.mcu_free(out)
+                assert got == one_shot, (threads, bands, route)

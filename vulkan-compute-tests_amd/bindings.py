@@ -357,6 +357,20 @@ class Context:
         _check(lib().mc_mandelbrot_render(self._h, C.byref(p), _ptr(rgba), _ptr(iters)), "mc_mandelbrot_render")
         return rgba, iters
 
+    def mandelbrot_banded(self, p, band_rows, rgba8=False):
+        """mc_mandelbrot_render_banded: the image (rows [row_begin, row_end)) rendered in pipelined row bands; returns the image — the fp32
+        storage buffer, or RGBA8 converted on the device — and the rows_done values the callback heard, in the order it heard them."""
+        rows = p.row_end - p.row_begin
+        out = np.empty((rows, p.width, 4), np.uint8 if rgba8 else np.float32)
+        heard = []
+        cb_t = C.CFUNCTYPE(None, C.c_uint32, C.c_void_p)
+        cb = cb_t(lambda done, user: heard.append(int(done)))
+        fn = lib().mc_mandelbrot_render_banded
+        fn.argtypes = [C.c_void_p, C.POINTER(MandelbrotParams), C.c_void_p, C.c_void_p, C.c_uint32, cb_t, C.c_void_p]
+        _check(fn(self._h, C.byref(p), None if rgba8 else _ptr(out), _ptr(out) if rgba8 else None, band_rows, cb, None),
+               "mc_mandelbrot_render_banded")
+        return out, heard
+
     def pathtrace(self, p, planes=None, spheres=None, acc=None, out=None):
         if planes is None or spheres is None:
             planes, spheres = default_scene()

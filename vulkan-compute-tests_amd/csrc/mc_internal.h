@@ -36,6 +36,8 @@ struct DeviceBuffer {
 struct mc_context {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // mc_mandelbrot_render_banded: odd bands (created on first use, or by the warm-up when told)
+    int ensure_stream2();
     hipDeviceProp_t props{};
     // colour LUT cache (Mandelbrot): rebuilt when (max_iter, k_color) changes
     mc::DeviceBuffer lut;
@@ -64,6 +66,8 @@ struct mc_context {
     // stream (mc_context_last_timing): t[0] before the first launch, t[1] after the last kernel, t[2] after the copy.
     hipEvent_t t_ev[3] = {nullptr, nullptr, nullptr};
     bool timing_valid = false;
+    bool banded_timing = false;          // the last blocking call was mc_mandelbrot_render_banded: its own two figures below
+    double banded_kernel_ms = 0.0, banded_copy_ms = 0.0;
     int mark(int k);      // records t_ev[k] on the context's stream (creating the events on first use)
 };
 

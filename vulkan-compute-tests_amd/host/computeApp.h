@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "mc_compute.h"
+#include "pngWriter.h"
 
 // The storage buffer's host side: page-locked memory from mc_host_alloc — what stands where the reference allocates its output
 // buffer HOST_VISIBLE | HOST_COHERENT and maps it (vulkanComputeApp.cpp:489-533, mandelbrotApp.h:153, pathtracerApp.h:206).
@@ -79,6 +80,16 @@ struct ComputeApp {
     //                  the helper works while the caller allocates its storage buffer in preRun();
     //   false          the round-5 order: the first launch, with everything it drags in, inside run().
     void setOverlapStart(bool o) { overlapStart = o; }
+    // Streamed save (round 6, the Mandelbrot app; the caller says beforehand that the image WILL be saved — main.cpp does): run() renders
+    // the image in pipelined row bands (mc_mandelbrot_render_banded) and hands every band that has arrived to the PNG writer's stripe
+    // workers, which filter and deflate it while the device renders the next ones; saveRenderedImage() then waits for the last stripes
+    // and writes the file.  The storage buffer (or the RGBA8
+    // image) is complete after run() as ever, the file is byte for byte the one the unstreamed save writes.  Off by default: run() alone
+    // does what the reference's does.  Not with --reference-png (lodepng::encode takes the finished image) or more than one GPU.
+    // kStreamAuto: only where it pays (worthStreaming(): the second stream of the pipelined render costs 9 ms to make and 9 ms at its
+    // first launch in a cold process — more than a render of a few milliseconds could hide).
+    enum { kStreamOff = 0, kStreamOn = 1, kStreamAuto = 2 };
+    void setStreamedSave(int mode) { streamedSave = mode; }
     // saveRenderedImage's file: a standard PNG of exactly the RGBA8 pixels the reference converts its buffer to (mandelbrotApp.h:159-174,
     // pathtracerApp.h:202-243), deflated stripe-parallel by pngWriter.h.  The reference encodes the same pixels with its vendored
     // third-party codec (lodepng::encode, mandelbrotApp.h:181 / pathtracerApp.h:245): a reference tree that calls this library
@@ -95,7 +106,9 @@ struct ComputeApp {
     // float -> u8 (+ rotation) loop, the PNG encoder + file write.
     // allocMs = the storage buffer's allocation (preRun()); warmupMs = the warm-up call on its helper thread, warmupWaitMs = what
     // run() still waited for it.
-    struct Timing { double allocMs = 0, runMs = 0, kernelMs = 0, copyMs = 0, convertMs = 0, pngMs = 0, warmupMs = 0, warmupWaitMs = 0; };
+    // streamedBands = row bands run() rendered with the PNG workers running beside it (0: the save was not streamed; then pngMs is all
+    // of the PNG work, otherwise what was left of it after run())
+    struct Timing { double allocMs = 0, runMs = 0, kernelMs = 0, copyMs = 0, convertMs = 0, pngMs = 0, warmupMs = 0, warmupWaitMs = 0; int streamedBands = 0; };
     const Timing& timing() const { return times; }
 
 protected:
@@ -114,6 +127,10 @@ protected:
     int pngThreads = 0;
     bool referencePng = false;
     bool overlapStart = true;
+    int streamedSave = kStreamOff;
+    virtual bool worthStreaming() const { return false; }
+    bool streaming() const { return !multi && !referencePng && (streamedSave == kStreamOn || (streamedSave == kStreamAuto && worthStreaming())); }
+    pngwriter::Progressive progressive;      // the save in progress while run() renders (streaming())
     std::thread warmThread;
     int warmStatus = MC_OK;
     std::string warmError;

@@ -30,6 +30,30 @@ int mcu_png_encode_storage(const float* vec4, uint32_t w, uint32_t h, float scal
     *out_len = png.size();
     return 0;
 }
+// The progressive encoder (pngwriter::Progressive) fed in `bands` steps from a source that is FILLED band by band: the destination the
+// workers read starts as garbage and each band is copied in just before it is declared ready — a worker that read a row too early
+// would encode the garbage.  rgba8_route = 0: the fp32 storage buffer; 1: an RGBA8 image with alpha 255.  Must give the one-shot file.
+int mcu_png_encode_progressive(const void* image, uint32_t w, uint32_t h, float scale, int rgba8_route, int threads, int bands, uint8_t** out,
+                               size_t* out_len) {
+    const size_t row = (size_t)w * (rgba8_route ? 4 : 16);
+    std::vector<uint8_t> live(row * h, 0xA5);
+    pngwriter::Progressive enc;
+    if (rgba8_route) enc.beginOpaqueRgba8(live.data(), w, h, threads);
+    else enc.beginStorage(reinterpret_cast<const float*>(live.data()), w, h, scale, threads);
+    if (bands < 1) bands = 1;
+    for (int b = 0; b < bands; b++) {
+        const uint32_t y0 = (uint32_t)((uint64_t)h * b / bands), y1 = (uint32_t)((uint64_t)h * (b + 1) / bands);
+        std::memcpy(live.data() + row * y0, static_cast<const uint8_t*>(image) + row * y0, row * (y1 - y0));
+        enc.rowsReady(y1);
+    }
+    std::vector<uint8_t> png;
+    if (!enc.finish(png).empty()) return 1;
+    *out = (uint8_t*)std::malloc(png.size());
+    if (!*out) return 2;
+    std::memcpy(*out, png.data(), png.size());
+    *out_len = png.size();
+    return 0;
+}
 void mcu_free(void* p) { std::free(p); }
 
 void mcu_float_to_u8(const float* in, uint8_t* out, size_t n) {

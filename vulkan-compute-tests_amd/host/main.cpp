@@ -34,6 +34,7 @@ int main(int argc, char* argv[]) {
     std::vector<const char*> pos;
     int gpus = 1;
     bool quiet = false, gpuPost = false, timingJson = false, referencePng = false, overlapStart = true, fullTeardown = false;
+    int streamedSave = ComputeApp::kStreamAuto;
     int pngThreads = 0;
     const char* outFile = nullptr;
     uint32_t width = 2000, height = 2000, maxIter = 128, precision = MC_PRECISION_F32, mathMode = MC_PT_MATH_STRICT;
@@ -70,6 +71,8 @@ int main(int argc, char* argv[]) {
             mathMode = choice(argv[++i], {{"strict", MC_PT_MATH_STRICT}, {"fast", MC_PT_MATH_FAST}, {"careful", MC_PT_MATH_FAST_CAREFUL}});
         }
         else if (a == "--reference-png") referencePng = true;       // the reference's lodepng::encode (make REFERENCE=<checkout>)
+        else if (a == "--no-streamed-save") streamedSave = ComputeApp::kStreamOff;   // render everything, then encode (see setStreamedSave)
+        else if (a == "--streamed-save") streamedSave = ComputeApp::kStreamOn;       // ... stream whatever the size (default: where it pays)
         else if (a == "--full-teardown") fullTeardown = true;        // run the destructors and the HIP runtime's exit handlers (see the end of main)
         else if (a == "--serial-start") overlapStart = false;        // measurements: the round-5 start-up order (no warm-up thread)
         else if (a == "--large-sphere-walls") largeSpheres = true;   // TEST_PRECISION_WITH_LARGE_SPHERE_WALLS (pathtracerApp.h:11)
@@ -101,6 +104,8 @@ int main(int argc, char* argv[]) {
     app.setGpuPostprocess(gpuPost);
     app.setPngThreads(pngThreads);
     app.setOverlapStart(overlapStart);
+    app.setStreamedSave(streamedSave);   // this program always saves what it renders (the Mandelbrot app streams; the path tracer's first
+                                         // output rows are its last storage rows, and its PNG is 3 ms beside a 14 ms kernel)
     if (referencePng && !ComputeApp::referencePngAvailable()) {   // said before anything is rendered
         printf("--reference-png: this binary was built without the reference's PNG codec; rebuild with `make REFERENCE=<checkout of "
                "pjhusky/vulkan-compute-tests>` (its src/external/lodepng is compiled where it lies)\n");
@@ -129,11 +134,11 @@ int main(int argc, char* argv[]) {
             const ComputeApp::Timing& t = app.timing();
             // (warmup = the warm-up call on its helper thread, warmup_wait = what run() still waited for it: computeApp.h)
             printf("{\"timing_ms\": {\"init\": %.3f, \"alloc\": %.3f, \"run\": %.3f, \"kernel\": %.3f, \"copy\": %.3f, \"convert\": %.3f, "
-                   "\"png\": %.3f, \"total\": %.3f, \"warmup\": %.3f, \"warmup_wait\": %.3f}, "
+                   "\"png\": %.3f, \"total\": %.3f, \"warmup\": %.3f, \"warmup_wait\": %.3f, \"streamed_bands\": %d}, "
                    "\"gpu_postprocess\": %s, \"gpus\": %d, \"overlap_start\": %s, \"reference_png\": %s, "
                    "\"main_at_ms\": %.3f, \"end_at_ms\": %.3f}\n",
                    initMs, t.allocMs, t.runMs, t.kernelMs, t.copyMs, t.convertMs, t.pngMs, since(tStart), t.warmupMs,
-                   t.warmupWaitMs, gpuPost ? "true" : "false", gpus, overlapStart ? "true" : "false", referencePng ? "true" : "false",
+                   t.warmupWaitMs, t.streamedBands, gpuPost ? "true" : "false", gpus, overlapStart ? "true" : "false", referencePng ? "true" : "false",
                    // CLOCK_MONOTONIC at main()'s first timed statement and now: a parent that reads the same clock around the process
                    // gets what `total` cannot contain — loading + static initialisers before main(), teardown after it
                    std::chrono::duration<double, std::milli>(tStart.time_since_epoch()).count(),

@@ -2,6 +2,7 @@
 #ifndef MANDELBROTAPP_H_
 #define MANDELBROTAPP_H_
 
+#include <algorithm>
 #include <chrono>
 
 #include "computeApp.h"
@@ -44,10 +45,11 @@ struct MandelbrotApp : public ComputeApp {
         mc_mandelbrot_params q = params;
         q.k_color[0] = 0.1f; q.k_color[1] = 0.7f; q.k_color[2] = 0.6f; q.k_color[3] = 0.0f;   // as createCommandBuffer sets it
         q.row_begin = 0; q.row_end = resy;
-        return mc_context_warmup_mandelbrot(ctx, &q, gpuPostprocess ? 1 : 0);
+        return mc_context_warmup_mandelbrot(ctx, &q, (gpuPostprocess ? 1 : 0) | (streaming() ? 2 : 0));   // (bit 1: the banded render's second stream)
     }
 
     virtual void runCommandBuffer() override {
+        if (streaming()) { runStreamed(); return; }
         if (gpuPostprocess) {   // render + float->u8 on the device: 4 B/pixel cross PCIe instead of 16
             if (multi) check(mc_multi_mandelbrot_render_rgba8(multi, &params, rgba8.bytes()), "mc_multi_mandelbrot_render_rgba8");
             else check(mc_mandelbrot_render_rgba8(ctx, &params, rgba8.bytes()), "mc_mandelbrot_render_rgba8");
@@ -67,6 +69,16 @@ struct MandelbrotApp : public ComputeApp {
         std::vector<uint8_t> image;
         constexpr float scaleFactor = 255.0f;   // mandelbrotApp.h:174
         auto t0 = std::chrono::steady_clock::now();
+        if (progressive.active()) {   // run() streamed the bands to the PNG workers: wait for the last stripes, write the file
+            printf("writing %s\n", png_filename);
+            std::vector<uint8_t> png;
+            std::string err = progressive.finish(png);
+            if (err.empty()) err = pngwriter::writeFile(png_filename, png);
+            if (!err.empty()) printf("encoder error: %s", err.c_str());
+            times.convertMs = 0.0;
+            times.pngMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            return;
+        }
         if (fusedSave()) {   // getRenderedImage's cast inside the PNG writer's stripe workers: one pass over the storage buffer
             printf("writing %s\n", png_filename);
             std::string err = writePngFromStorage(png_filename, resx, resy, scaleFactor, false);
@@ -87,6 +99,24 @@ struct MandelbrotApp : public ComputeApp {
     const HostStorage& storageBuffer() const { return buffer; }
 
 private:
+    // The image in row bands of kBandRows through mc_mandelbrot_render_banded: band k + 1 is launched on a second stream before band k has
+    // finished, and every band is handed to the PNG workers as it arrives.  At K4 (5120 rows: 8 bands) the 50 ms of filter + deflate run
+    // beside the 60 ms of rendering instead of after them.  (A blocking render per band was measured first: every band's last tiles then
+    // drain on an otherwise empty device — K4's kernels 72 ms instead of 60, profiles/r06_streamed_save_probe_blocking_bands.txt.)
+    static constexpr uint32_t kBandRows = 640;
+    // Where streaming pays: K4 (7680 x 5120, M = 50 000: 60 ms of rendering beside 50 ms of PNG work) gains 29 ms of 204; K1 (3200 x 2400,
+    // M = 1000: a 0.2 ms kernel, 2 ms of copy) LOSES 10 to the second stream's first launch (profiles/r06_streamed_save_probe.txt).  The
+    // work bound W x H x M tells the two apart before anything has run; the line sits a decade above K1 and a decade below K4.
+    virtual bool worthStreaming() const override { return (double)resx * (double)resy * (double)params.max_iter >= 1e11; }
+    static void bandArrived(uint32_t rowsDone, void* self) { static_cast<MandelbrotApp*>(self)->progressive.rowsReady(rowsDone); }
+    void runStreamed() {
+        constexpr float scaleFactor = 255.0f;   // mandelbrotApp.h:174
+        if (gpuPostprocess) progressive.beginOpaqueRgba8(rgba8.bytes(), resx, resy, pngThreads);   // (the device conversion writes alpha 255)
+        else progressive.beginStorage(buffer.data(), resx, resy, scaleFactor, pngThreads);
+        check(mc_mandelbrot_render_banded(ctx, &params, gpuPostprocess ? nullptr : buffer.data(), gpuPostprocess ? rgba8.bytes() : nullptr,
+                                          kBandRows, &MandelbrotApp::bandArrived, this), "mc_mandelbrot_render_banded");
+        times.streamedBands = (int)((resy + kBandRows - 1) / kBandRows);
+    }
     struct Pixel { float r, g, b, a; };   // mandelbrotApp.h:187-189
     static void split(double d, float& hi, float& lo) { hi = (float)d; lo = (float)(d - (double)hi); }
     uint64_t bufferSize;

@@ -9,8 +9,8 @@
 #include <cstring>
 #include <sched.h>
 
-#include <cstdlib>
-#include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 namespace pngwriter {
@@ -215,61 +215,91 @@ int usableThreads() {
 }
 
 namespace {
-std::string encode_rows(std::vector<uint8_t>& out, const RowSource& src, int threads) {
-    const uint32_t w = src.w, h = src.h;
-    const int bpp = src.bpp;
-    const bool opaque = bpp == 3;
-    // stripes of >= 64 KiB of raw data, at most 4 per worker thread
-    if (threads <= 0) threads = usableThreads();
-    threads = std::max(1, std::min(threads, 64));
-    const size_t row_bytes = (size_t)w * bpp + 1;
-    uint32_t min_rows = (uint32_t)std::max<size_t>(1, (64 * 1024 + row_bytes - 1) / row_bytes);
-    uint32_t n_stripes = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)threads * 4u, h / min_rows ? h / min_rows : 1));
-    if (threads == 1) n_stripes = 1;
-    std::vector<Stripe> stripes(n_stripes);
-    for (uint32_t i = 0; i < n_stripes; i++) {
-        stripes[i].y0 = (uint32_t)((uint64_t)h * i / n_stripes);
-        stripes[i].y1 = (uint32_t)((uint64_t)h * (i + 1) / n_stripes);
-    }
+// The stripe plan, the workers and the assembly of one image.  The rows of the source may still be ARRIVING, in order (Progressive
+// below): a worker takes the stripes in ascending order and, before it filters one, waits until the source's rows [0, y1) are final —
+// rows_ready(h) before the start makes this the plain encoder.  The stripes, and therefore the file, do not depend on how the rows came.
+struct EncodeJob {
+    RowSource src;
+    int threads = 1;
+    uint32_t n_stripes = 1;
+    std::vector<Stripe> stripes;
     std::atomic<uint32_t> next{0};
-    auto worker = [&]() {
+    std::mutex mu;
+    std::condition_variable cv;
+    uint32_t ready = 0;            // rows [0, ready) of the source are final (guarded by mu)
+    std::vector<std::thread> workers;
+
+    EncodeJob(const RowSource& source, int nthreads) : src(source) {
+        const uint32_t h = src.h;
+        // stripes of >= 64 KiB of raw data, at most 4 per worker thread
+        threads = nthreads <= 0 ? usableThreads() : nthreads;
+        threads = std::max(1, std::min(threads, 64));
+        const size_t row_bytes = (size_t)src.w * src.bpp + 1;
+        const uint32_t min_rows = (uint32_t)std::max<size_t>(1, (64 * 1024 + row_bytes - 1) / row_bytes);
+        n_stripes = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)threads * 4u, h / min_rows ? h / min_rows : 1));
+        if (threads == 1) n_stripes = 1;
+        stripes.resize(n_stripes);
+        for (uint32_t i = 0; i < n_stripes; i++) {
+            stripes[i].y0 = (uint32_t)((uint64_t)h * i / n_stripes);
+            stripes[i].y1 = (uint32_t)((uint64_t)h * (i + 1) / n_stripes);
+        }
+    }
+    void rows_ready(uint32_t up_to) {
+        { std::lock_guard<std::mutex> lk(mu); ready = std::max(ready, std::min(up_to, src.h)); }
+        cv.notify_all();
+    }
+    void work() {
         for (;;) {
-            uint32_t i = next.fetch_add(1);
+            const uint32_t i = next.fetch_add(1);
             if (i >= n_stripes) break;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return ready >= stripes[i].y1; }); }
             compress_stripe(src, i + 1 == n_stripes, stripes[i]);
         }
-    };
-    int nt = (int)std::min<uint32_t>((uint32_t)threads, n_stripes);
-    if (nt <= 1) worker();
-    else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; t++) th.emplace_back(worker);
-        for (auto& t : th) t.join();
     }
-    size_t zlen = 2 + 4;
-    uLong adler = adler32(0L, Z_NULL, 0);
-    for (auto& s : stripes) {
-        if (!s.ok) return "zlib deflate failed";
-        zlen += s.z.size();
-        adler = adler32_combine(adler, s.adler, (z_off_t)s.raw_len);
+    void start() {   // background workers (Progressive); run() below works on the calling thread as well
+        const int nt = (int)std::min<uint32_t>((uint32_t)threads, n_stripes);
+        for (int t = 0; t < nt; t++) workers.emplace_back([this] { work(); });
     }
-    std::vector<uint8_t> z;
-    z.reserve(zlen);
-    z.push_back(0x78); z.push_back(0x9c);   // zlib header: deflate, 32 KiB window, default compression
-    for (auto& s : stripes) z.insert(z.end(), s.z.begin(), s.z.end());
-    put32(z, (uint32_t)adler);
+    void join() {
+        for (auto& t : workers) t.join();
+        workers.clear();
+    }
+    std::string assemble(std::vector<uint8_t>& out) {
+        const uint32_t w = src.w, h = src.h;
+        const bool opaque = src.bpp == 3;
+        size_t zlen = 2 + 4;
+        uLong adler = adler32(0L, Z_NULL, 0);
+        for (auto& s : stripes) {
+            if (!s.ok) return "zlib deflate failed";
+            zlen += s.z.size();
+            adler = adler32_combine(adler, s.adler, (z_off_t)s.raw_len);
+        }
+        std::vector<uint8_t> z;
+        z.reserve(zlen);
+        z.push_back(0x78); z.push_back(0x9c);   // zlib header: deflate, 32 KiB window, default compression
+        for (auto& s : stripes) z.insert(z.end(), s.z.begin(), s.z.end());
+        put32(z, (uint32_t)adler);
 
-    out.clear();
-    out.reserve(z.size() + 64);
-    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
-    out.insert(out.end(), sig, sig + 8);
-    std::vector<uint8_t> ihdr;
-    put32(ihdr, w); put32(ihdr, h);
-    ihdr.push_back(8); ihdr.push_back(opaque ? 2 : 6); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
-    chunk_header_and_crc(out, "IHDR", ihdr.data(), ihdr.size());
-    chunk_header_and_crc(out, "IDAT", z.data(), z.size());
-    chunk_header_and_crc(out, "IEND", nullptr, 0);
-    return "";
+        out.clear();
+        out.reserve(z.size() + 64);
+        static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+        out.insert(out.end(), sig, sig + 8);
+        std::vector<uint8_t> ihdr;
+        put32(ihdr, w); put32(ihdr, h);
+        ihdr.push_back(8); ihdr.push_back(opaque ? 2 : 6); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+        chunk_header_and_crc(out, "IHDR", ihdr.data(), ihdr.size());
+        chunk_header_and_crc(out, "IDAT", z.data(), z.size());
+        chunk_header_and_crc(out, "IEND", nullptr, 0);
+        return "";
+    }
+};
+
+std::string encode_rows(std::vector<uint8_t>& out, const RowSource& src, int threads) {
+    EncodeJob job(src, threads);
+    job.rows_ready(src.h);
+    if (std::min<uint32_t>((uint32_t)job.threads, job.n_stripes) <= 1) job.work();
+    else { job.start(); job.join(); }
+    return job.assemble(out);
 }
 
 std::string write_file(const char* filename, const std::vector<uint8_t>& png) {
@@ -298,6 +328,34 @@ std::string encodeStorage(std::vector<uint8_t>& out, const float* vec4, uint32_t
     src.vec4 = vec4; src.scale = scale; src.rotate180 = rotate180; src.w = w; src.h = h; src.bpp = 3;
     return encode_rows(out, src, threads);
 }
+
+struct Progressive::Impl { EncodeJob job; Impl(const RowSource& s, int t) : job(s, t) {} };
+Progressive::Progressive() = default;
+Progressive::~Progressive() {
+    if (impl) { impl->job.rows_ready(impl->job.src.h); impl->job.join(); }   // (abandoned: let the workers run out — the source must still be alive)
+}
+void Progressive::beginStorage(const float* vec4, uint32_t w, uint32_t h, float scale, int threads) {
+    RowSource src;
+    src.vec4 = vec4; src.scale = scale; src.rotate180 = false; src.w = w; src.h = h; src.bpp = 3;
+    impl.reset(new Impl(src, threads));
+    impl->job.start();
+}
+void Progressive::beginOpaqueRgba8(const uint8_t* rgba8, uint32_t w, uint32_t h, int threads) {
+    RowSource src;
+    src.rgba8 = rgba8; src.w = w; src.h = h; src.bpp = 3;
+    impl.reset(new Impl(src, threads));
+    impl->job.start();
+}
+void Progressive::rowsReady(uint32_t upTo) { if (impl) impl->job.rows_ready(upTo); }
+std::string Progressive::finish(std::vector<uint8_t>& png) {
+    if (!impl) return "no image in progress";
+    impl->job.rows_ready(impl->job.src.h);
+    impl->job.join();
+    std::string err = impl->job.assemble(png);
+    impl.reset();
+    return err;
+}
+std::string writeFile(const char* filename, const std::vector<uint8_t>& png) { return write_file(filename, png); }
 
 std::string encodeFile(const char* filename, const uint8_t* rgba8, uint32_t w, uint32_t h, int threads) {
     std::vector<uint8_t> png;

@@ -8,6 +8,7 @@
 #define PNGWRITER_H_
 
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -39,6 +40,28 @@ std::string encodeFile(const char* filename, const uint8_t* rgba8, uint32_t w, u
 // the one convertStorage + encode produce with the same thread count.
 std::string encodeStorage(std::vector<uint8_t>& out, const float* vec4, uint32_t w, uint32_t h, float scale, bool rotate180, int threads = 0);
 std::string encodeStorageFile(const char* filename, const float* vec4, uint32_t w, uint32_t h, float scale, bool rotate180, int threads = 0);
+
+// The same encoder fed while the image is still being PRODUCED, top rows first (round 6: the Mandelbrot app renders its image in row
+// bands and the stripe workers filter and deflate band k while the device renders band k + 1 — at K4 the 50 ms of PNG work were a quarter
+// of the process).  begin*() starts the workers, which wait; rowsReady(y) declares the source's rows [0, y) final; finish() waits for the
+// last stripe and returns the file.  Same stripes, same bytes as encodeStorage / encode with the same thread count.  The source buffer
+// must outlive the object.  No point reflection here (the path tracer's first output rows are its storage buffer's LAST ones).
+class Progressive {
+public:
+    Progressive();
+    ~Progressive();
+    Progressive(const Progressive&) = delete;
+    Progressive& operator=(const Progressive&) = delete;
+    void beginStorage(const float* vec4, uint32_t w, uint32_t h, float scale, int threads = 0);
+    void beginOpaqueRgba8(const uint8_t* rgba8, uint32_t w, uint32_t h, int threads = 0);   // alpha is 255 by construction: stored as RGB
+    void rowsReady(uint32_t upTo);
+    bool active() const { return (bool)impl; }
+    std::string finish(std::vector<uint8_t>& png);
+private:
+    struct Impl;
+    std::unique_ptr<Impl> impl;
+};
+std::string writeFile(const char* filename, const std::vector<uint8_t>& png);
 }  // namespace pngwriter
 
 #endif  // PNGWRITER_H_
