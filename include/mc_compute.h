@@ -28,10 +28,12 @@
 extern "C" {
 #endif
 
-/* 2 (round 6): + mc_assemble_rgba8_device_async, mc_context_warmup_*; since 1 (round 5 additions, un-bumped then): mc_build_id,
+/* 3 (end of round 6): + mc_mandelbrot_render_banded, row bands in mc_mandelbrot_render_rgba8, scene-class bit 32 (MC_PT_SCENE_SPECULAR),
+ * bit 1 of mc_context_warmup_mandelbrot's last argument.
+ * 2 (round 6): + mc_assemble_rgba8_device_async, mc_context_warmup_*; since 1 (round 5 additions, un-bumped then): mc_build_id,
  * mc_host_alloc / mc_host_free, mc_context_last_timing, math_mode 2, scene-class bit 16; the measurement flag enums moved to
  * mc_compute_test.h.  A binder checks mc_abi_version() against the MC_ABI_VERSION it was written for. */
-#define MC_ABI_VERSION 2
+#define MC_ABI_VERSION 3
 
 typedef enum mc_status {
     MC_OK = 0,

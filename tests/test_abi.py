@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol(B):
     assert len(names) >= 25
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.mc_abi_version() == B.ABI_VERSION == 2
+    assert L.mc_abi_version() == B.ABI_VERSION == 3
 
 
 def test_test_hooks_live_in_their_own_library(B):

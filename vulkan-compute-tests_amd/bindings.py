@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MC_LIB_PATH") or os.path.join(_HERE, "lib", "libmc_co
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mc_compute.h")
 
 MC_OK = 0
-ABI_VERSION = 2   # MC_ABI_VERSION of include/mc_compute.h this binding is written against
+ABI_VERSION = 3   # MC_ABI_VERSION of include/mc_compute.h this binding is written against
 PRECISION_F32, PRECISION_DS = 0, 1
 PT_MATH_STRICT, PT_MATH_FAST, PT_MATH_FAST_CAREFUL = 0, 1, 2
 MANDEL_FMA = 1
