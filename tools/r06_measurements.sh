@@ -57,6 +57,9 @@ mirrors3)   # ... and 64 rooms the rule has not seen (seed 9)                   
 mirrors4)   # ... 64 more unseen rooms (seed 10), the rule unchanged whatever they show                         -> profiles/r06_fast_tolerance_scenes_validation2.txt
   timeout -k 10 1100 python tools/fast_tolerance_scenes.py --scenes 64 --spp 500 --seed 10 > $out/r06_fast_tolerance_scenes_validation2.txt 2>&1 || exit 1
   tail -n 3 $out/r06_fast_tolerance_scenes_validation2.txt ;;
+mirrors5)   # ... and 64 more (seed 11)                                                                          -> profiles/r06_fast_tolerance_scenes_validation3.txt
+  timeout -k 10 1100 python tools/fast_tolerance_scenes.py --scenes 64 --spp 500 --seed 11 > $out/r06_fast_tolerance_scenes_validation3.txt 2>&1 || exit 1
+  tail -n 3 $out/r06_fast_tolerance_scenes_validation3.txt ;;
 tests)
   timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $out/r06_gputest.log 2>&1; rc=$?; tail -5 $out/r06_gputest.log; [ $rc -eq 0 ] || exit $rc ;;
 *) echo "usage: $0 <section> ..."; exit 2 ;;
