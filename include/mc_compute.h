@@ -137,8 +137,8 @@ enum {
                            /* The library renders the request with the tier MEASURED to hold that bound on scenes like the one given: */
                            /* the fast tier (gfx950 hardware rcp/rsq/sqrt/sin/cos/exp/log, a*b+c contracted) for a scene with no more  */
                            /* specular surface than the reference scene's (mc_pathtrace_scene_class: up to three spheres, diffuse     */
-                           /* walls, mirror / glass spheres no larger) — the reference scene reads 2.49, 149 random scenes of that     */
-                           /* class at most 3.8 but for one at 4.2: met where it was stated, measured and not guaranteed around it;     */
+                           /* walls, mirror / glass spheres no larger) — the reference scene reads 2.49, 174 random scenes of that     */
+                           /* class at most 3.8 but for two at 4.2: met where it was stated, measured and not guaranteed around it;     */
                            /* the careful tier below everywhere else (at most 1.8 on every scene measured); the strict kernels for a  */
                            /* light all but enclosed by an opaque sphere.  mc_pathtrace_select_kernel reports which                     */
                            /* (mc_pathtrace_kernel_info.math_mode).  A caller that needs the margin on EVERY scene asks for the tier below. */
@@ -254,10 +254,10 @@ int mc_context_warmup_mandelbrot(mc_context* ctx, const mc_mandelbrot_params* p,
  * MC_PT_MATH_FAST request for such a scene is rendered by the careful tier (MC_PT_MATH_FAST_CAREFUL).  Bit 5 (MC_PT_SCENE_SPECULAR) — any
  * scene with up to three spheres that has more specular surface than the reference scene (pathtracerApp.h:14-39: diffuse walls, one mirror
  * and one glass sphere of r = 0.8): a mirror or glass wall, or mirror spheres (material 2), or glass spheres (material 3), whose squared radii
- * sum to more than 0.65.  A forked sample that a specular chain carries to a light moves its pixel by the light's whole emission: of 212
- * jittered three-sphere rooms fifteen are outside the bound in the fast tier (up to 8.0) — twelve of the 101 with a specular wall, two of
- * the 30 with larger mirror spheres, ONE of the 81 this bit leaves to the fast tier (4.2; the others at most 3.8; 50 of them drawn after
- * the rule was set: profiles/r06_fast_tolerance_scenes*.txt).  The careful tier renders the 131 others at 0.8 or less. */
+ * sum to more than 0.65.  A forked sample that a specular chain carries to a light moves its pixel by the light's whole emission: of 276
+ * jittered three-sphere rooms eighteen are outside the bound in the fast tier (up to 8.0) — fourteen of the 132 with a specular wall, two of
+ * the 38 with larger mirror spheres, TWO of the 106 this bit leaves to the fast tier (4.2; the others at most 3.8; 76 of them drawn after
+ * the rule was set: profiles/r06_fast_tolerance_scenes*.txt).  The careful tier renders the 170 others at 0.8 or less. */
 #define MC_PT_SCENE_SLAB 1u
 #define MC_PT_SCENE_LIGHTS_INSIDE 2u
 #define MC_PT_SCENE_SPHERES_DISJOINT 4u   /* slab scenes: the spheres are pairwise disjoint (the fast pool kernel then needs no square roots for shadow rays) */

@@ -10,12 +10,12 @@
 // lit) goes the other way — the sample "forks" to another valid path.  The share of forked samples grows with the specular surface a path
 // can run through, and a fork that a specular chain carries to a light moves its pixel by the light's whole emission: the fast tier keeps
 // the stated tolerance (RMSE 0.5 / 99.9-percentile L2 4 at 500 spp) on boxes with up to three spheres, misses it on 2 of 44 random boxes with
-// four, reads 3.2 at five and exceeds the bound from six on (p99.9 4.4 .. 5.6) — and misses it on 12 of 101 three-sphere rooms with a mirror or
+// four, reads 3.2 at five and exceeds the bound from six on (p99.9 4.4 .. 5.6) — and misses it on 14 of 132 three-sphere rooms with a mirror or
 // glass wall (up to 8.0).  Since round 6 the host switches at FOUR spheres and wherever a scene has more specular surface than the reference
 // scene's (csrc/pathtrace.hip: kCarefulSpheres, kFastSpecularArea).  The census (tools/fork_census.py, profiles/r05_fork_census*.txt) shows
 // what carries the forks: contraction and the hardware seeds' last bit, in equal parts — not any one shortcut.  With both removed the
 // same scenes read 1.9 .. 3.0; with the two identities whose forks are one-sided (tools/fork_bias.py) in the reference's form as well,
-// 0.65 .. 1.14 at 1.14 .. 1.43 of the fast tier's time (profiles/r05_fast_tiers.txt; the strict kernels: 2.35 x); the 131 promoted rooms of
+// 0.65 .. 1.14 at 1.14 .. 1.43 of the fast tier's time (profiles/r05_fast_tiers.txt; the strict kernels: 2.35 x); the 170 promoted rooms of
 // round 6 read at most 0.80 (profiles/r06_fast_tolerance_scenes*.txt).  The host selects this tier for an MC_PT_MATH_FAST request on such a
 // scene (mc_pathtrace_scene_class bits 4 and 5), and for an explicit MC_PT_MATH_FAST_CAREFUL one.
 #include "pathtrace_kernel.h"
