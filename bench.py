@@ -627,6 +627,14 @@ def multi_block(job, args):
                                     "steps": pl["single_steps"], "device": job.device_index,
                                     "note": "rank 0 alone on its GPU, the whole image, same job, same timing method; the other ranks idle"},
                      "retained_per_gpu": (mm["value"] / n) / single["value"],
+                     # north_star: "as absolute numbers and as fraction of the fp32-ALU roofline" at every N — the whole job's
+                     # algorithmic flops per second (wall time of the timed steps, exchange included) over N x the one-GPU peak
+                     "roofline": {"bound": "valu", "unit": "TFLOP/s", "achieved": mm["value"] * mm["flops_per_unit"] / 1e12,
+                                  "peak": PEAK_FP32_TFLOPS * n, "frac": mm["value"] * mm["flops_per_unit"] / 1e12 / (PEAK_FP32_TFLOPS * n),
+                                  "single_gpu_frac": single["value"] * mm["flops_per_unit"] / 1e12 / PEAK_FP32_TFLOPS,
+                                  "flops_per_unit": mm["flops_per_unit"],
+                                  "basis": "algorithmic flops of all ranks / max-over-ranks wall time of the timed steps (exchange "
+                                           "included), over N x 157.3 TFLOP/s"},
                      "equal_to_single_gpu": equal, "checks": checks}
             del single
         del mm, f32_again

@@ -151,7 +151,8 @@ def test_two_rank_rehearsal_mandelbrot_exchanges_iteration_counts():
 
 
 MULTI_KEYS = ("workload", "metric", "unit", "scaling", "value", "ms_per_step", "image", "n_gpus", "world_size", "ranks", "exchange",
-              "exchange_async", "gather_ms_rank0", "gather_bytes_per_rank", "single_gpu", "retained_per_gpu", "equal_to_single_gpu", "checks")
+              "exchange_async", "gather_ms_rank0", "gather_bytes_per_rank", "single_gpu", "retained_per_gpu", "roofline",
+              "equal_to_single_gpu", "checks")
 
 
 @pytest.mark.parametrize("n", [2, 4])
@@ -183,6 +184,9 @@ def test_plain_command_carries_the_8gpu_configurations(n):
         assert e["equal_to_single_gpu"] is True and all(v for v in e["checks"].values() if isinstance(v, bool))
         assert e["exchange_async"] is False                                      # (the rehearsal backend stages through the host)
         assert e["single_gpu"]["value"] > 0 and abs(e["retained_per_gpu"] - e["value"] / n / e["single_gpu"]["value"]) < 1e-9
+        rf = e["roofline"]      # north_star: the fraction of the fp32-ALU roofline at every N (whole job over N x the one-GPU peak)
+        assert rf["peak"] == pytest.approx(157.3 * n) and rf["frac"] == pytest.approx(e["value"] * rf["flops_per_unit"] / 1e12 / (157.3 * n))
+        assert rf["frac"] == pytest.approx(rf["single_gpu_frac"] * e["retained_per_gpu"])
     k3, k4 = mb["K3"], mb["K4"]
     assert k3["gather_bytes_per_rank"] == 4 * 3840 * (2560 // n) and "RGBA8" in k3["exchange"]           # 4 B/pixel
     assert set(k3["checks"]) == {"rgba8_image", "f32_storage_buffer"}
