@@ -161,3 +161,20 @@ def test_progressive_encoder_gives_the_one_shot_file(H, O, w, h):
                 got = C.string_at(out, n.value)
                 H.mcu_free(out)
                 assert got == one_shot, (threads, bands, route)
+
+
+@pytest.mark.parametrize("route", [0, 1])
+def test_an_abandoned_progressive_save_never_reads_rows_that_did_not_arrive(B, route):
+    """A streamed save whose render fails (run() throws, the application object is torn down): pngwriter::Progressive must stop its
+    workers WITHOUT reading the rows that never arrived — its source may already be gone by then (the apps' storage buffer is a later
+    member than the encoder, so it is destroyed first).  The helper maps the image with every row from `ready` on inaccessible, reports the
+    first rows and destroys the encoder: a read beyond them is a fault, so the call runs in a child process."""
+    import subprocess
+    import sys
+    lib = os.environ.get("MC_HOSTUTIL_LIB_PATH") or os.path.join(os.path.dirname(B.LIB_PATH), "libmc_hostutil.so")
+    code = ("import ctypes as C, sys; H = C.CDLL(sys.argv[1]); "
+            "H.mcu_png_progressive_abandon.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint32]; "
+            "rcs = [H.mcu_png_progressive_abandon(1500, 1100, int(sys.argv[2]), t, ready) for t in (1, 3, 0) for ready in (0, 1, 300, 1099, 1100)]; "
+            "sys.exit(1 if any(rcs) else 0)")
+    p = subprocess.run([sys.executable, "-c", code, lib, str(route)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, (p.returncode, p.stderr[-500:])

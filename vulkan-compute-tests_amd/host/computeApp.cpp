@@ -32,6 +32,7 @@ void ComputeApp::setReferencePng(bool r) {
 }
 
 ComputeApp::~ComputeApp() {
+    progressive.abandon();   // a streamed save whose render failed: its workers stop before the buffers they read are released below
     if (warmThread.joinable()) warmThread.join();
     // cleanupVulkanResources (vulkanComputeApp.cpp:673-695)
     if (multi) mc_multi_destroy(multi);

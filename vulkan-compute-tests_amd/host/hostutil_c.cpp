@@ -3,6 +3,9 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include "pngWriter.h"
 
 extern "C" {
@@ -52,6 +55,34 @@ int mcu_png_encode_progressive(const void* image, uint32_t w, uint32_t h, float 
     if (!*out) return 2;
     std::memcpy(*out, png.data(), png.size());
     *out_len = png.size();
+    return 0;
+}
+// An image that is never finished (the render that was to fill it failed): the encoder is begun on a mapping whose rows from
+// `ready_rows` on are INACCESSIBLE (PROT_NONE from the next page boundary), hears of the first `ready_rows` rows and is then destroyed.
+// A worker that read a row it was never promised — the old destructor declared every row ready and let the workers run out — faults.
+// Returns 0 when the object was torn down without such a read, and the number of stripes' worth of time is bounded (no worker waits).
+int mcu_png_progressive_abandon(uint32_t w, uint32_t h, int rgba8_route, int threads, uint32_t ready_rows) {
+    const size_t row = (size_t)w * (rgba8_route ? 4 : 16), page = (size_t)sysconf(_SC_PAGESIZE);
+    const size_t bytes = ((row * h + page - 1) / page + 1) * page;
+    void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) return 2;
+    std::memset(m, 0x3c, bytes);
+    if (ready_rows > h) ready_rows = h;
+    const size_t first_dead = ((row * ready_rows + page - 1) / page) * page;
+    if (first_dead < bytes && mprotect(static_cast<char*>(m) + first_dead, bytes - first_dead, PROT_NONE) != 0) { munmap(m, bytes); return 3; }
+    {
+        pngwriter::Progressive enc;
+        if (rgba8_route) enc.beginOpaqueRgba8(static_cast<const uint8_t*>(m), w, h, threads);
+        else enc.beginStorage(static_cast<const float*>(m), w, h, 1.0f, threads);
+        enc.rowsReady(ready_rows);
+    }   // ~Progressive: abandon()
+    {
+        pngwriter::Progressive enc;   // ... and abandon() by name, after which the object is idle again
+        enc.beginOpaqueRgba8(static_cast<const uint8_t*>(m), w, h, threads);
+        enc.abandon();
+        if (enc.active()) { munmap(m, bytes); return 4; }
+    }
+    munmap(m, bytes);
     return 0;
 }
 void mcu_free(void* p) { std::free(p); }

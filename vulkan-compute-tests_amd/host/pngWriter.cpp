@@ -227,6 +227,7 @@ struct EncodeJob {
     std::mutex mu;
     std::condition_variable cv;
     uint32_t ready = 0;            // rows [0, ready) of the source are final (guarded by mu)
+    bool cancelled = false;        // the image will never be finished: workers take no further stripe (guarded by mu)
     std::vector<std::thread> workers;
 
     EncodeJob(const RowSource& source, int nthreads) : src(source) {
@@ -248,11 +249,21 @@ struct EncodeJob {
         { std::lock_guard<std::mutex> lk(mu); ready = std::max(ready, std::min(up_to, src.h)); }
         cv.notify_all();
     }
+    // An abandoned image (the render that was to fill the source failed): no worker reads a row it has not been promised, none takes
+    // another stripe, and join() returns once the stripes already in hand — whose rows WERE final — are done.
+    void cancel() {
+        { std::lock_guard<std::mutex> lk(mu); cancelled = true; }
+        cv.notify_all();
+    }
     void work() {
         for (;;) {
             const uint32_t i = next.fetch_add(1);
             if (i >= n_stripes) break;
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return ready >= stripes[i].y1; }); }
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return cancelled || ready >= stripes[i].y1; });
+                if (cancelled) break;
+            }
             compress_stripe(src, i + 1 == n_stripes, stripes[i]);
         }
     }
@@ -331,8 +342,14 @@ std::string encodeStorage(std::vector<uint8_t>& out, const float* vec4, uint32_t
 
 struct Progressive::Impl { EncodeJob job; Impl(const RowSource& s, int t) : job(s, t) {} };
 Progressive::Progressive() = default;
-Progressive::~Progressive() {
-    if (impl) { impl->job.rows_ready(impl->job.src.h); impl->job.join(); }   // (abandoned: let the workers run out — the source must still be alive)
+Progressive::~Progressive() { abandon(); }
+// The image will not be finished (run() threw): the workers stop WITHOUT reading rows that never arrived — by the time an application
+// object is torn down its storage buffer may be gone already (members are destroyed in reverse order of declaration).
+void Progressive::abandon() {
+    if (!impl) return;
+    impl->job.cancel();
+    impl->job.join();
+    impl.reset();
 }
 void Progressive::beginStorage(const float* vec4, uint32_t w, uint32_t h, float scale, int threads) {
     RowSource src;

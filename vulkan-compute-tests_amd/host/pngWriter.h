@@ -45,7 +45,8 @@ std::string encodeStorageFile(const char* filename, const float* vec4, uint32_t 
 // bands and the stripe workers filter and deflate band k while the device renders band k + 1 — at K4 the 50 ms of PNG work were a quarter
 // of the process).  begin*() starts the workers, which wait; rowsReady(y) declares the source's rows [0, y) final; finish() waits for the
 // last stripe and returns the file.  Same stripes, same bytes as encodeStorage / encode with the same thread count.  The source buffer
-// must outlive the object.  No point reflection here (the path tracer's first output rows are its storage buffer's LAST ones).
+// must stay alive until finish() or abandon() has returned (an object destroyed with an image in progress abandons it: rows that were never
+// declared ready are never read).  No point reflection here (the path tracer's first output rows are its storage buffer's LAST ones).
 class Progressive {
 public:
     Progressive();
@@ -57,6 +58,7 @@ public:
     void rowsReady(uint32_t upTo);
     bool active() const { return (bool)impl; }
     std::string finish(std::vector<uint8_t>& png);
+    void abandon();   // the image will never be complete: stops the workers without another read of the source (the destructor does this)
 private:
     struct Impl;
     std::unique_ptr<Impl> impl;
