@@ -115,6 +115,9 @@ protected:
     void createBuffer(uint64_t bufferSizeBytes);   // vulkanComputeApp.cpp:489-533: the output storage buffer (gpuPostprocess: a quarter
                                                    // of it, for the RGBA8 image)
     void waitWarmup();                             // before the first call on ctx after init(): joins the warm-up helper
+    // First statement of every derived destructor: the helper calls the derived class's warmup(), which reads the derived object's scene
+    // tables and parameters — an object torn down before run() (preRun() threw) must not release them under the helper's feet.
+    void joinWarmupQuietly() noexcept { if (warmThread.joinable()) warmThread.join(); }
     virtual int warmup() { return MC_OK; }                // apps: mc_context_warmup_* for the request run() will make (helper thread)
     static void check(int status, const char* what);
 

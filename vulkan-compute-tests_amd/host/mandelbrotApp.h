@@ -18,7 +18,7 @@ struct MandelbrotApp : public ComputeApp {
         bufferSize = (uint64_t)sizeof(Pixel) * resx * resy;   // mandelbrotApp.h:16 (uint32_t there)
         mc_mandelbrot_default_params(resx, resy, &params);    // M=128, centre (-0.445,0), scale 2.34, kColor {0.1,0.7,0.6,0}
     }
-    virtual ~MandelbrotApp() {}
+    virtual ~MandelbrotApp() { joinWarmupQuietly(); }
 
     // -- additions: the reference hard-codes these in the shader (mandelbrot.comp:5-6,38,40) --
     void setMaxIter(uint32_t m) { params.max_iter = m; }

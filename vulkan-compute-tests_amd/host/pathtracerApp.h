@@ -35,7 +35,7 @@ struct PathtracerApp : public ComputeApp {
         planes.assign(pl, pl + 12 * np);
         spheres.assign(sp, sp + 12 * ns);
     }
-    virtual ~PathtracerApp() {}
+    virtual ~PathtracerApp() { joinWarmupQuietly(); }   // (the helper reads planes / spheres)
 
     // -- additions --
     void setMathMode(uint32_t mode) { params.math_mode = mode; }   // MC_PT_MATH_STRICT / MC_PT_MATH_FAST / MC_PT_MATH_FAST_CAREFUL
