@@ -42,7 +42,7 @@ typedef enum mc_status {
     MC_ERR_HIP = 3,              /* a HIP runtime call failed; see mc_last_error_detail()             */
     MC_ERR_RCCL = 4,             /* an RCCL call failed                                               */
     MC_ERR_UNSUPPORTED = 5,      /* e.g. scene larger than the on-chip scene store                    */
-    MC_ERR_OUT_OF_MEMORY = 6
+    MC_ERR_OUT_OF_MEMORY = 6     /* a device allocation failed; mc_host_alloc: more than this process may still take */
 } mc_status;
 
 typedef struct mc_context mc_context; /* opaque: device, stream, scratch, LUT cache, (optional) RCCL comms */

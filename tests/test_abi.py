@@ -429,3 +429,19 @@ def test_round6_entry_points_validate_without_gpu(B):
     assert L.mc_mandelbrot_render_banded(None, None, None, None, 64, None, None) == 1
     out = subprocess.check_output(["readelf", "-d", B.LIB_PATH], text=True)
     assert "librccl" not in out and "libamdhip64" in out
+
+
+def test_host_alloc_refuses_what_the_process_cannot_take(B):
+    """mc_host_alloc touches (or pins) every page it hands out: a request beyond MemAvailable / the cgroup's room would end in the
+    kernel's out-of-memory killer instead of an error code (16 B x W x H of a mistyped resolution is all it takes).  Refused up front,
+    before a page is touched and before any device call — so this holds on a machine without a GPU too."""
+    L = B.lib()
+    L.mc_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    L.mc_last_error_detail.restype = C.c_char_p
+    L.mc_error_string.restype = C.c_char_p
+    p = C.c_void_p(1)
+    rc = L.mc_host_alloc(1 << 50, C.byref(p))
+    assert rc == 6 and p.value is None                       # MC_ERR_OUT_OF_MEMORY, nothing handed out
+    assert b"page-locked host memory" in L.mc_error_string(rc)
+    detail = L.mc_last_error_detail().decode()
+    assert str(1 << 50) in detail and "available to this process" in detail
