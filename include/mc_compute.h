@@ -70,7 +70,9 @@ int mc_context_device_info(mc_context* ctx, char* name, size_t name_len, int* co
  * the runtime (K4's 629 MB: 4 ms instead of hipHostMalloc's 86, same copy rate; profiles/r06_hostmem_probe.txt), smaller ones
  * hipHostMalloc.  Any host pointer is accepted by the render calls — a pageable one is copied at nearly the same rate once its pages
  * are resident, at half of it while they are not — so these two are an ownership convention, not a requirement.
- * Usable before any context exists; the memory is visible to every device of the node. */
+ * Usable before any context exists; the memory is visible to every device of the node.  Every page handed out is touched or pinned:
+ * a request beyond what the process may still take (MemAvailable, the room under a cgroup memory limit) returns MC_ERR_OUT_OF_MEMORY
+ * before a page is touched (mc_last_error_detail names both figures) — it would otherwise meet the out-of-memory killer. */
 int mc_host_alloc(size_t bytes, void** out_ptr);
 int mc_host_free(void* ptr);
 

@@ -414,3 +414,22 @@ def test_reference_png_mode_writes_the_reference_bytes(B, O, tmp_path):
         r = subprocess.run([os.path.join(bindir, "pathtracer"), "--reference-png", "--quiet"] + extra, capture_output=True, text=True, cwd=tmp_path)
         assert r.returncode == 0, r.stdout + r.stderr
         assert open(tmp_path / "pathtracer.png", "rb").read() == want_p
+
+
+def test_apps_fail_cleanly_on_an_image_no_memory_holds(B, tmp_path):
+    """The failure path of the reference flow (main.cpp:35-38: message, EXIT_FAILURE) with the round-6 helpers in play: a storage
+    buffer of 16 B x 6 000 000 x 4 000 000 = 384 TB can be neither page-locked (mc_host_alloc refuses it before touching a page:
+    MC_ERR_OUT_OF_MEMORY) nor reserved on the device (the warm-up helper's request fails at the same time, on its own thread).
+    preRun() throws while the helper may still be running; the object is torn down — derived destructor joins the helper before the
+    scene tables go, the base abandons any encoder, the context is destroyed — and the process returns EXIT_FAILURE: no signal, no
+    hang, no file."""
+    bindir = os.path.join(os.path.dirname(os.path.dirname(B.LIB_PATH)), "bin")
+    runs = [[os.path.join(bindir, "pathtracer"), "1", "4000000", "--quiet"],
+            [os.path.join(bindir, "pathtracer"), "1", "4000000", "--quiet", "--gpu-postprocess", "--math", "fast"],
+            [os.path.join(bindir, "mandelbrot"), "--width", "4000000", "--height", "4000000", "--quiet"],
+            [os.path.join(bindir, "mandelbrot"), "--width", "4000000", "--height", "4000000", "--quiet", "--gpu-postprocess", "--serial-start"]]
+    for cmd in runs:
+        r = subprocess.run(cmd + ["--out", "never.png"], capture_output=True, text=True, cwd=tmp_path, timeout=120)
+        assert r.returncode == 1, (cmd, r.returncode, r.stdout[-400:], r.stderr[-400:])      # EXIT_FAILURE — not a signal (negative)
+        assert "mc_host_alloc" in r.stdout and "page-locked host memory" in r.stdout, r.stdout[-400:]
+        assert not (tmp_path / "never.png").exists()
