@@ -8,6 +8,7 @@
 extern "C" {
 int mcu_png_encode_storage(const float*, uint32_t, uint32_t, float, int, int, uint8_t**, size_t*);
 int mcu_png_encode_progressive(const void*, uint32_t, uint32_t, float, int, int, int, uint8_t**, size_t*);
+int mcu_png_progressive_abandon(uint32_t, uint32_t, int, int, uint32_t);
 void mcu_free(void*);
 }
 int main() {
@@ -27,6 +28,11 @@ int main() {
         }
         mcu_free(a);
     }
+    // an image abandoned half-way (the cancel / wake-up / join of the workers, both routes)
+    for (int threads : {1, 4, 8})
+        for (uint32_t ready : {0u, 1u, 350u, 700u})
+            for (int route : {0, 1})
+                if (mcu_png_progressive_abandon(w, h, route, threads, ready)) bad++;
     printf("mismatches %d\n", bad);
     return bad != 0;
 }
