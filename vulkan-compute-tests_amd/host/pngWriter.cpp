@@ -144,10 +144,25 @@ void filter_rows(const RowSource& src, uint32_t y0, uint32_t y1, uint8_t* raw) {
     }
 }
 
+// Bytes that are NOT zero-filled on allocation: a std::vector sized to deflateBound() memsets — and thereby faults in — as many bytes as
+// the raw image has, of which deflate then writes a twentieth; the filtered rows are overwritten in full anyway.
+struct Bytes {
+    std::unique_ptr<uint8_t[]> p;
+    size_t n = 0;
+    void allocate(size_t bytes) { p.reset(new uint8_t[bytes]); n = bytes; }
+    uint8_t* data() { return p.get(); }
+    const uint8_t* data() const { return p.get(); }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    const uint8_t* begin() const { return p.get(); }
+    const uint8_t* end() const { return p.get() + n; }
+};
+
 struct Stripe {
     uint32_t y0 = 0, y1 = 0;
-    std::vector<uint8_t> z;   // raw deflate bytes of this stripe (sync-flushed, or finished for the last one)
+    Bytes z;   // raw deflate bytes of this stripe (sync-flushed, or finished for the last one); z.n = the bytes deflate wrote
     uLong adler = 1;
+    uLong crc = 0;            // CRC-32 of z: the IDAT chunk's CRC is combined from these (crc32_combine), not recomputed over the stream
     size_t raw_len = 0;
     bool ok = false;
 };
@@ -156,7 +171,8 @@ struct Stripe {
 // block), so the concatenation of all stripes is ONE valid deflate stream (the pigz construction).
 void compress_stripe(const RowSource& src, bool last, Stripe& s) {
     const size_t stride = (size_t)src.w * src.bpp;
-    std::vector<uint8_t> raw((stride + 1) * (size_t)(s.y1 - s.y0));
+    Bytes raw;
+    raw.allocate((stride + 1) * (size_t)(s.y1 - s.y0));   // (every byte is written by filter_rows)
     filter_rows(src, s.y0, s.y1, raw.data());
     s.raw_len = raw.size();
     uLong ad = adler32(0L, Z_NULL, 0);
@@ -172,13 +188,20 @@ void compress_stripe(const RowSource& src, bool last, Stripe& s) {
     // K1's 3200 x 2400 image and on a 900 x 600 path trace against the default strategy at level 6 — 159 against 228 ms and 23 against
     // 66 ms of CPU, and the files are SMALLER (909 871 / 915 268 bytes, 1 233 340 / 1 251 549): the hash-chain search finds nothing better.
     if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_RLE) != Z_OK) return;
-    s.z.resize(deflateBound(&zs, (uLong)raw.size()) + 16);
+    s.z.allocate(deflateBound(&zs, (uLong)raw.size()) + 16);
     zs.next_in = raw.data(); zs.avail_in = (uInt)raw.size();
     zs.next_out = s.z.data(); zs.avail_out = (uInt)s.z.size();
     int rc = deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);
     s.ok = last ? rc == Z_STREAM_END : (rc == Z_OK && zs.avail_in == 0);
-    s.z.resize(s.z.size() - zs.avail_out);
+    s.z.n = s.z.size() - zs.avail_out;   // (the allocation stays as large as it was; only these bytes were touched)
     deflateEnd(&zs);
+    uLong c = crc32(0L, Z_NULL, 0);
+    for (size_t pos = 0; pos < s.z.size();) {
+        uInt n = (uInt)std::min<size_t>(s.z.size() - pos, 1u << 30);
+        c = crc32(c, s.z.data() + pos, n);
+        pos += n;
+    }
+    s.crc = c;
 }
 
 }  // namespace
@@ -218,6 +241,12 @@ namespace {
 // The stripe plan, the workers and the assembly of one image.  The rows of the source may still be ARRIVING, in order (Progressive
 // below): a worker takes the stripes in ascending order and, before it filters one, waits until the source's rows [0, y1) are final —
 // rows_ready(h) before the start makes this the plain encoder.  The stripes, and therefore the file, do not depend on how the rows came.
+// Stripes per worker thread.  Eight: when the rows arrive in bands (Progressive) the LAST band's stripes are all that is left to do once the
+// device is done, and with four per thread a band of an eighth of the image was 8 stripes for 16 workers — half of them idle for the 12 ms
+// that mattered.  With Z_RLE (no match window to lose) a stripe boundary costs an empty stored block: K4's file grows by 0.02 %.
+#ifndef MC_PNG_STRIPES_PER_THREAD
+#define MC_PNG_STRIPES_PER_THREAD 8
+#endif
 struct EncodeJob {
     RowSource src;
     int threads = 1;
@@ -232,12 +261,12 @@ struct EncodeJob {
 
     EncodeJob(const RowSource& source, int nthreads) : src(source) {
         const uint32_t h = src.h;
-        // stripes of >= 64 KiB of raw data, at most 4 per worker thread
+        // stripes of >= 64 KiB of raw data, at most MC_PNG_STRIPES_PER_THREAD per worker thread
         threads = nthreads <= 0 ? usableThreads() : nthreads;
         threads = std::max(1, std::min(threads, 64));
         const size_t row_bytes = (size_t)src.w * src.bpp + 1;
         const uint32_t min_rows = (uint32_t)std::max<size_t>(1, (64 * 1024 + row_bytes - 1) / row_bytes);
-        n_stripes = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)threads * 4u, h / min_rows ? h / min_rows : 1));
+        n_stripes = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)threads * (uint32_t)MC_PNG_STRIPES_PER_THREAD, h / min_rows ? h / min_rows : 1));
         if (threads == 1) n_stripes = 1;
         stripes.resize(n_stripes);
         for (uint32_t i = 0; i < n_stripes; i++) {
@@ -285,21 +314,32 @@ struct EncodeJob {
             zlen += s.z.size();
             adler = adler32_combine(adler, s.adler, (z_off_t)s.raw_len);
         }
-        std::vector<uint8_t> z;
-        z.reserve(zlen);
-        z.push_back(0x78); z.push_back(0x9c);   // zlib header: deflate, 32 KiB window, default compression
-        for (auto& s : stripes) z.insert(z.end(), s.z.begin(), s.z.end());
-        put32(z, (uint32_t)adler);
+        // One copy of every stripe, straight into the file image, and NO pass over the assembled stream: the chunk's CRC is joined from
+        // the stripes' own (computed by the workers) with crc32_combine.  The serial tail of a save was two copies and a CRC pass over
+        // the whole stream — at K4 (7.9 MB) most of what was left to do after the last band had arrived.
+        const uint8_t zhdr[2] = {0x78, 0x9c};   // zlib header: deflate, 32 KiB window, default compression
+        const uint8_t ztail[4] = {(uint8_t)(adler >> 24), (uint8_t)(adler >> 16), (uint8_t)(adler >> 8), (uint8_t)adler};
+        uLong crc = crc32(0L, reinterpret_cast<const Bytef*>("IDAT"), 4);
+        crc = crc32(crc, zhdr, 2);
+        for (auto& s : stripes)
+            if (!s.z.empty()) crc = crc32_combine(crc, s.crc, (z_off_t)s.z.size());
+        crc = crc32(crc, ztail, 4);
 
         out.clear();
-        out.reserve(z.size() + 64);
+        out.reserve(zlen + 8 + 25 + 12 + 12);
         static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
         out.insert(out.end(), sig, sig + 8);
         std::vector<uint8_t> ihdr;
         put32(ihdr, w); put32(ihdr, h);
         ihdr.push_back(8); ihdr.push_back(opaque ? 2 : 6); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
         chunk_header_and_crc(out, "IHDR", ihdr.data(), ihdr.size());
-        chunk_header_and_crc(out, "IDAT", z.data(), z.size());
+        put32(out, (uint32_t)zlen);
+        static const uint8_t idat[4] = {'I', 'D', 'A', 'T'};
+        out.insert(out.end(), idat, idat + 4);
+        out.insert(out.end(), zhdr, zhdr + 2);
+        for (auto& s : stripes) out.insert(out.end(), s.z.begin(), s.z.end());
+        out.insert(out.end(), ztail, ztail + 4);
+        put32(out, (uint32_t)crc);
         chunk_header_and_crc(out, "IEND", nullptr, 0);
         return "";
     }
@@ -340,17 +380,17 @@ std::string encodeStorage(std::vector<uint8_t>& out, const float* vec4, uint32_t
     return encode_rows(out, src, threads);
 }
 
-struct Progressive::Impl { EncodeJob job; Impl(const RowSource& s, int t) : job(s, t) {} };
+struct Progressive::Impl { EncodeJob job; bool finished = false; Impl(const RowSource& s, int t) : job(s, t) {} };
 Progressive::Progressive() = default;
 Progressive::~Progressive() { abandon(); }
 // The image will not be finished (run() threw): the workers stop WITHOUT reading rows that never arrived — by the time an application
 // object is torn down its storage buffer may be gone already (members are destroyed in reverse order of declaration).
 void Progressive::abandon() {
     if (!impl) return;
-    impl->job.cancel();
-    impl->job.join();
+    if (!impl->finished) { impl->job.cancel(); impl->job.join(); }
     impl.reset();
 }
+bool Progressive::active() const { return impl && !impl->finished; }
 void Progressive::beginStorage(const float* vec4, uint32_t w, uint32_t h, float scale, int threads) {
     RowSource src;
     src.vec4 = vec4; src.scale = scale; src.rotate180 = false; src.w = w; src.h = h; src.bpp = 3;
@@ -366,10 +406,13 @@ void Progressive::beginOpaqueRgba8(const uint8_t* rgba8, uint32_t w, uint32_t h,
 void Progressive::rowsReady(uint32_t upTo) { if (impl) impl->job.rows_ready(upTo); }
 std::string Progressive::finish(std::vector<uint8_t>& png) {
     if (!impl) return "no image in progress";
+    if (impl->finished) return "no image in progress";
     impl->job.rows_ready(impl->job.src.h);
     impl->job.join();
     std::string err = impl->job.assemble(png);
-    impl.reset();
+    // The stripes' buffers are released by the next begin*() or the destructor, not here: the caller still has the file to write, and an
+    // application that leaves with _Exit once it is written never pays for giving the memory back (5 ms at K4).
+    impl->finished = true;
     return err;
 }
 std::string writeFile(const char* filename, const std::vector<uint8_t>& png) { return write_file(filename, png); }

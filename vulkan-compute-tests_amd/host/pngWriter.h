@@ -56,7 +56,7 @@ public:
     void beginStorage(const float* vec4, uint32_t w, uint32_t h, float scale, int threads = 0);
     void beginOpaqueRgba8(const uint8_t* rgba8, uint32_t w, uint32_t h, int threads = 0);   // alpha is 255 by construction: stored as RGB
     void rowsReady(uint32_t upTo);
-    bool active() const { return (bool)impl; }
+    bool active() const;   // an image is in progress (begun, neither finished nor abandoned)
     std::string finish(std::vector<uint8_t>& png);
     void abandon();   // the image will never be complete: stops the workers without another read of the source (the destructor does this)
 private:
