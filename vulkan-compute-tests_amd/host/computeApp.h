@@ -108,7 +108,8 @@ struct ComputeApp {
     // run() still waited for it.
     // streamedBands = row bands run() rendered with the PNG workers running beside it (0: the save was not streamed; then pngMs is all
     // of the PNG work, otherwise what was left of it after run())
-    struct Timing { double allocMs = 0, runMs = 0, kernelMs = 0, copyMs = 0, convertMs = 0, pngMs = 0, warmupMs = 0, warmupWaitMs = 0; int streamedBands = 0; };
+    struct Timing { double allocMs = 0, runMs = 0, kernelMs = 0, copyMs = 0, convertMs = 0, pngMs = 0, warmupMs = 0, warmupWaitMs = 0; int streamedBands = 0;
+                    double pngJoinMs = 0, pngAssembleMs = 0, pngWriteMs = 0; };   // a streamed save's tail: last stripes, file image, write
     const Timing& timing() const { return times; }
 
 protected:

@@ -134,11 +134,12 @@ int main(int argc, char* argv[]) {
             const ComputeApp::Timing& t = app.timing();
             // (warmup = the warm-up call on its helper thread, warmup_wait = what run() still waited for it: computeApp.h)
             printf("{\"timing_ms\": {\"init\": %.3f, \"alloc\": %.3f, \"run\": %.3f, \"kernel\": %.3f, \"copy\": %.3f, \"convert\": %.3f, "
-                   "\"png\": %.3f, \"total\": %.3f, \"warmup\": %.3f, \"warmup_wait\": %.3f, \"streamed_bands\": %d}, "
+                   "\"png\": %.3f, \"total\": %.3f, \"warmup\": %.3f, \"warmup_wait\": %.3f, \"streamed_bands\": %d, "
+                   "\"png_join\": %.3f, \"png_assemble\": %.3f, \"png_write\": %.3f}, "
                    "\"gpu_postprocess\": %s, \"gpus\": %d, \"overlap_start\": %s, \"reference_png\": %s, "
                    "\"main_at_ms\": %.3f, \"end_at_ms\": %.3f}\n",
                    initMs, t.allocMs, t.runMs, t.kernelMs, t.copyMs, t.convertMs, t.pngMs, since(tStart), t.warmupMs,
-                   t.warmupWaitMs, t.streamedBands, gpuPost ? "true" : "false", gpus, overlapStart ? "true" : "false", referencePng ? "true" : "false",
+                   t.warmupWaitMs, t.streamedBands, t.pngJoinMs, t.pngAssembleMs, t.pngWriteMs, gpuPost ? "true" : "false", gpus, overlapStart ? "true" : "false", referencePng ? "true" : "false",
                    // CLOCK_MONOTONIC at main()'s first timed statement and now: a parent that reads the same clock around the process
                    // gets what `total` cannot contain — loading + static initialisers before main(), teardown after it
                    std::chrono::duration<double, std::milli>(tStart.time_since_epoch()).count(),

@@ -73,7 +73,10 @@ struct MandelbrotApp : public ComputeApp {
             printf("writing %s\n", png_filename);
             std::vector<uint8_t> png;
             std::string err = progressive.finish(png);
+            times.pngJoinMs = progressive.lastJoinMs(); times.pngAssembleMs = progressive.lastAssembleMs();
+            auto tw = std::chrono::steady_clock::now();
             if (err.empty()) err = pngwriter::writeFile(png_filename, png);
+            times.pngWriteMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
             if (!err.empty()) printf("encoder error: %s", err.c_str());
             times.convertMs = 0.0;
             times.pngMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

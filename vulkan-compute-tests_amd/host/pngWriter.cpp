@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -407,9 +408,14 @@ void Progressive::rowsReady(uint32_t upTo) { if (impl) impl->job.rows_ready(upTo
 std::string Progressive::finish(std::vector<uint8_t>& png) {
     if (!impl) return "no image in progress";
     if (impl->finished) return "no image in progress";
+    auto ms = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
     impl->job.rows_ready(impl->job.src.h);
+    auto t0 = std::chrono::steady_clock::now();
     impl->job.join();
+    joinMs = ms(t0);
+    t0 = std::chrono::steady_clock::now();
     std::string err = impl->job.assemble(png);
+    assembleMs = ms(t0);
     // The stripes' buffers are released by the next begin*() or the destructor, not here: the caller still has the file to write, and an
     // application that leaves with _Exit once it is written never pays for giving the memory back (5 ms at K4).
     impl->finished = true;

@@ -58,10 +58,13 @@ public:
     void rowsReady(uint32_t upTo);
     bool active() const;   // an image is in progress (begun, neither finished nor abandoned)
     std::string finish(std::vector<uint8_t>& png);
+    double lastJoinMs() const { return joinMs; }          // finish(): waiting for the last stripes ...
+    double lastAssembleMs() const { return assembleMs; }  // ... and putting the file image together
     void abandon();   // the image will never be complete: stops the workers without another read of the source (the destructor does this)
 private:
     struct Impl;
     std::unique_ptr<Impl> impl;
+    double joinMs = 0.0, assembleMs = 0.0;
 };
 std::string writeFile(const char* filename, const std::vector<uint8_t>& png);
 }  // namespace pngwriter
