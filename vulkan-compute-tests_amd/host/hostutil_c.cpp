@@ -81,6 +81,12 @@ int mcu_png_progressive_abandon(uint32_t w, uint32_t h, int rgba8_route, int thr
         enc.beginOpaqueRgba8(static_cast<const uint8_t*>(m), w, h, threads);
         enc.abandon();
         if (enc.active()) { munmap(m, bytes); return 4; }
+        // ... and a begin on top of an image in progress (run() twice, no save between) gives the first one up the same way
+        enc.beginOpaqueRgba8(static_cast<const uint8_t*>(m), w, h, threads);
+        enc.rowsReady(ready_rows);
+        enc.beginOpaqueRgba8(static_cast<const uint8_t*>(m), w, h, threads);
+        if (!enc.active()) { munmap(m, bytes); return 5; }
+        enc.abandon();
     }
     munmap(m, bytes);
     return 0;

@@ -395,12 +395,14 @@ bool Progressive::active() const { return impl && !impl->finished; }
 void Progressive::beginStorage(const float* vec4, uint32_t w, uint32_t h, float scale, int threads) {
     RowSource src;
     src.vec4 = vec4; src.scale = scale; src.rotate180 = false; src.w = w; src.h = h; src.bpp = 3;
+    abandon();   // (an image still in progress — run() called again before a save — is given up, its workers stopped, not destroyed under them)
     impl.reset(new Impl(src, threads));
     impl->job.start();
 }
 void Progressive::beginOpaqueRgba8(const uint8_t* rgba8, uint32_t w, uint32_t h, int threads) {
     RowSource src;
     src.rgba8 = rgba8; src.w = w; src.h = h; src.bpp = 3;
+    abandon();   // (an image still in progress — run() called again before a save — is given up, its workers stopped, not destroyed under them)
     impl.reset(new Impl(src, threads));
     impl->job.start();
 }
