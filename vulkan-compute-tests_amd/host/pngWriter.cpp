@@ -170,10 +170,13 @@ struct Stripe {
 
 // One stripe: filter + raw deflate.  Non-final stripes end on a byte boundary with Z_SYNC_FLUSH (an empty stored
 // block), so the concatenation of all stripes is ONE valid deflate stream (the pigz construction).
-void compress_stripe(const RowSource& src, bool last, Stripe& s) {
+// `scratch` is the calling worker's buffer for the filtered rows, reused from stripe to stripe: a fresh one per stripe faulted in as many
+// pages as the raw image has — in a cold process (the apps are one) every one of them for the first time.
+void compress_stripe(const RowSource& src, bool last, Stripe& s, Bytes& scratch) {
     const size_t stride = (size_t)src.w * src.bpp;
-    Bytes raw;
-    raw.allocate((stride + 1) * (size_t)(s.y1 - s.y0));   // (every byte is written by filter_rows)
+    const size_t raw_bytes = (stride + 1) * (size_t)(s.y1 - s.y0);
+    if (scratch.size() < raw_bytes) scratch.allocate(raw_bytes);   // (every byte used is written by filter_rows)
+    struct View { uint8_t* p; size_t n; uint8_t* data() const { return p; } size_t size() const { return n; } } raw{scratch.data(), raw_bytes};
     filter_rows(src, s.y0, s.y1, raw.data());
     s.raw_len = raw.size();
     uLong ad = adler32(0L, Z_NULL, 0);
@@ -286,6 +289,7 @@ struct EncodeJob {
         cv.notify_all();
     }
     void work() {
+        Bytes scratch;   // this worker's filtered rows (compress_stripe)
         for (;;) {
             const uint32_t i = next.fetch_add(1);
             if (i >= n_stripes) break;
@@ -294,7 +298,7 @@ struct EncodeJob {
                 cv.wait(lk, [&] { return cancelled || ready >= stripes[i].y1; });
                 if (cancelled) break;
             }
-            compress_stripe(src, i + 1 == n_stripes, stripes[i]);
+            compress_stripe(src, i + 1 == n_stripes, stripes[i], scratch);
         }
     }
     void start() {   // background workers (Progressive); run() below works on the calling thread as well
